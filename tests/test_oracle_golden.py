@@ -1,0 +1,101 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) against fixtures produced by the REAL
+reference (oracle/gen_golden.py, run in the build container).  CPU-only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from versband_amd import synth
+
+SEED = 1234
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dit_sd():
+    return {E: synth.make_state_dict(synth.dit_shapes(synth.DiTConfig(num_experts=E)), SEED) for E in (4, 8)}
+
+
+@pytest.mark.parametrize("tag,E", [("e4", 4), ("e8", 8)])
+@pytest.mark.parametrize("dense", [False, True])
+def test_dit_forward_matches_reference(golden_dir, dit_sd, tag, E, dense):
+    g = _load(golden_dir, f"dit_forward_{tag}.npz")
+    B, T, L, E_, _ = g["meta"]
+    assert E_ == E
+    sd = dit_sd[E]
+    x = torch.from_numpy(g["x"])
+    midi, beats = torch.from_numpy(g["midi"]), torch.from_numpy(g["beats"])
+    for br, key in ((0, "t5_cond"), (1, "t5_uncond")):
+        cond = ref_cpu.dit_precompute(sd, torch.from_numpy(g[key]), midi, beats, int(T))
+        noise = [tuple(torch.from_numpy(g[f"noise{br}_{i}_{j}"]) for j in range(3)) for i in range(4)]
+        v = ref_cpu.dit_forward(sd, x, torch.from_numpy(g["t_idx"]), cond, noise, dense=dense)
+        assert _rel(v, g[f"v{br}"]) < 2e-6, (br, _rel(v, g[f"v{br}"]))
+
+
+def test_t_index_tables(golden_dir):
+    g = _load(golden_dir, "t_index_tables.npz")
+    for n in (10, 24, 50):
+        _, idx = ref_cpu.t_index_table(n + 1)
+        assert idx == list(g[f"tidx{n}"])
+    # the quantisation quirk of SURVEY Q3 is really there
+    assert list(g["tidx50"])[5] == 99 and list(g["tidx50"])[10] == 199
+
+
+def test_vae_decode_matches_reference(golden_dir):
+    g = _load(golden_dir, "vae_decode.npz")
+    sd = synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), SEED + 1)
+    mel = ref_cpu.vae_decode(sd, torch.from_numpy(g["z"]))
+    assert _rel(mel, g["mel"]) < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["v1", "rb2"])
+def test_hifigan_matches_reference(golden_dir, tag):
+    g = _load(golden_dir, f"hifigan_{tag}.npz")
+    cfg = synth.HifiGanConfig() if tag == "v1" else synth.HifiGanConfig(
+        resblock="2", upsample_rates=(8, 8, 5), upsample_kernel_sizes=(16, 16, 11), upsample_initial_channel=128,
+        resblock_kernel_sizes=(3, 5), resblock_dilation_sizes=((1, 3), (1, 3)))
+    sd = synth.make_state_dict(synth.hifigan_shapes(cfg), SEED + 2)
+    wav = ref_cpu.hifigan_forward(sd, cfg.as_hparams(), torch.from_numpy(g["mel"]))
+    assert wav.shape == g["wav"].shape
+    assert _rel(wav, g["wav"]) < 2e-6
+
+
+def test_sample_cfg_and_decode_match_reference(golden_dir, dit_sd):
+    g = _load(golden_dir, "sample_cfg_3step.npz")
+    B, T, L, E, seed, steps = [int(v) for v in g["meta"]]
+    sd = dit_sd[E]
+    midi, beats = torch.from_numpy(g["midi"]), torch.from_numpy(g["beats"])
+    cc = ref_cpu.dit_precompute(sd, torch.from_numpy(g["t5_cond"]), midi, beats, T)
+    cu = ref_cpu.dit_precompute(sd, torch.from_numpy(g["t5_uncond"]), midi, beats, T)
+
+    def noise_fn(k, br):
+        out = []
+        for i in range(4):
+            out.append(tuple(torch.from_numpy(np.concatenate(
+                [synth.gumbel_exponentials(seed, b, 2 * k + br, i, gate, T, w) for b in range(B)], 0))
+                for gate, w in ((0, 2), (1, E), (2, E))))
+        return out
+    z, traj = ref_cpu.sample_cfg(sd, torch.from_numpy(g["x"]), cc, cu, float(g["scale"]), steps + 1, noise_fn,
+                                 return_traj=True)
+    assert _rel(traj, g["traj"]) < 5e-6
+    assert _rel(z, g["z"]) < 5e-6
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), SEED + 1)
+    mel = ref_cpu.vae_decode(sdv, z, scale_factor=float(g["scale_factor"]))
+    assert _rel(mel, g["mel"]) < 5e-6
+
+
+def test_router_top1_tie_break_and_weight():
+    logits = torch.tensor([[1.0, 1.0, 0.5, 1.0], [0.0, 2.0, 2.0, -1.0]])
+    idx, w = ref_cpu.router_top1(logits, torch.zeros_like(logits))
+    assert idx.tolist() == [0, 1]
+    assert torch.allclose(w, torch.ones(2), atol=2e-7)
