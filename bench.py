@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-seconds generated per second (BASELINE.json metric).
+
+A "step" = one pass of the whole hot path over one batch of synthetic clips that are already
+resident in HBM: conditioning precompute -> 50 Euler flow steps with CFG (2 network evaluations
+per step, batched) -> VAE decode -> full HiFi-GAN decode.  Workload = BASELINE.json configs[1]:
+batch 8 x 20 s clips, bf16 DiT + fp32 VAE/vocoder, random-init checkpoints of the configured
+architecture (synthetic, no network).  N>1: one process per GPU, clips sharded by rank (weak
+scaling), weights broadcast once from rank 0 over RCCL, no data-path collective.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CLIP_SECONDS = 20.0
+T_LAT, L_CTX = 752, 80
+SEED = 1234
+PEAK = {0: ("mfma", 2500.0, "bf16 MFMA GEMM (DiT projections + experts)"),
+        1: ("mfma", 2500.0, "bf16 flash attention"),
+        2: ("mfma", 157.3, "fp32 MFMA implicit-GEMM conv1d (VAE + HiFi-GAN)")}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--flow-steps", type=int, default=50)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
+    ap.add_argument("--scale", type=float, default=3.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-flow-steps", type=int, default=6)
+    return ap.parse_args()
+
+
+def broadcast_state(sds, rank, world, device):
+    """rank 0's checkpoints -> every rank, one flat RCCL broadcast (the only collective of the path)."""
+    import torch.distributed as dist
+    flat_keys = [(i, k) for i, sd in enumerate(sds) for k in sd]
+    sizes = [sds[i][k].numel() for i, k in flat_keys]
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if rank == 0:
+        off = 0
+        for (i, k), n in zip(flat_keys, sizes):
+            buf[off:off + n].copy_(sds[i][k].reshape(-1))
+            off += n
+    dist.broadcast(buf, src=0)
+    off = 0
+    out = [dict() for _ in sds]
+    for (i, k), n in zip(flat_keys, sizes):
+        out[i][k] = buf[off:off + n].view(sds[i][k].shape)
+        off += n
+    return out
+
+
+def cpu_baseline(sd_d, sd_v, sd_h, hp, flow_steps_total, cpu_steps, scale):
+    """The CPU oracle (a port of the reference's algorithm, routed + hoisted variant) on the host cores:
+    B=1, one 20 s clip; `cpu_steps` Euler steps are timed and extrapolated linearly to the full count,
+    VAE decode and HiFi-GAN are timed in full."""
+    from oracle import ref_cpu
+    from tests.helpers import clip_batch, exp_noise
+    from versband_amd import model as vm
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    inp = clip_batch(1, T_LAT, L_CTX, clip0=0, seed=SEED)
+    t0 = time.perf_counter()
+    cc = ref_cpu.dit_precompute(sd_d, inp["t5_cond"], inp["midi"], inp["beats"], T_LAT)
+    cu = ref_cpu.dit_precompute(sd_d, inp["t5_uncond"], inp["midi"], inp["beats"], T_LAT)
+    t_pre = time.perf_counter() - t0
+    noise = {(k, br): exp_noise(1, T_LAT, 4, 2 * k + br, 4, seed=SEED) for k in range(cpu_steps) for br in (0, 1)}
+    t0 = time.perf_counter()
+    z = ref_cpu.sample_cfg(sd_d, inp["x_latent"], cc, cu, scale, flow_steps_total + 1,
+                           lambda k, br: noise[(k, br)]) if cpu_steps >= flow_steps_total else None
+    if z is None:      # bounded sample: run cpu_steps Euler steps of the same schedule
+        t_span, idx = ref_cpu.t_index_table(flow_steps_total + 1)
+        x = inp["x_latent"].clone()
+        for k in range(cpu_steps):
+            ti = torch.full((1,), idx[k], dtype=torch.long)
+            e_c = ref_cpu.dit_forward(sd_d, x, ti, cc, noise[(k, 0)])
+            e_u = ref_cpu.dit_forward(sd_d, x, ti, cu, noise[(k, 1)])
+            x = x + (t_span[k + 1] - t_span[k]) * (e_u + scale * (e_c - e_u))
+        z = x
+    t_flow = (time.perf_counter() - t0) * (flow_steps_total / float(min(cpu_steps, flow_steps_total)))
+    t0 = time.perf_counter()
+    mel = ref_cpu.vae_decode(sd_v, z)
+    t_vae = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref_cpu.hifigan_forward(sd_h, hp, mel)
+    t_voc = time.perf_counter() - t0
+    total = t_pre + t_flow + t_vae + t_voc
+    return {"value": CLIP_SECONDS / total, "unit": "mel-s/s", "cores": cores, "kind": "port",
+            "sample": f"B=1 x 20 s clip on {cores} threads: cond precompute {t_pre:.2f}s + {min(cpu_steps, flow_steps_total)} of "
+                      f"{flow_steps_total} CFG Euler steps timed and scaled to {t_flow:.1f}s + full VAE decode {t_vae:.2f}s + "
+                      f"full HiFi-GAN {t_voc:.2f}s (torch fp32 oracle, routed experts, conditioning hoisted)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
+    torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    from tests.helpers import clip_batch
+    from versband_amd import _lib as L
+    from versband_amd import model as vm
+    from versband_amd import synth
+    from versband_amd.engine import Context, DiTEngine, build_hifigan, build_vae_decoder
+
+    dcfg, vcfg, hcfg = synth.DiTConfig(), synth.VAEConfig(), synth.HifiGanConfig()
+    shapes = [synth.dit_shapes(dcfg), synth.vae_decoder_shapes(vcfg), synth.hifigan_shapes(hcfg)]
+    if rank == 0:
+        sds = [synth.make_state_dict(s, SEED + i) for i, s in enumerate(shapes)]
+    else:
+        sds = [{k: torch.empty(shp) for k, (shp, _) in s.items()} for s in shapes]
+    sds_cpu = sds
+    if world > 1:
+        sds = broadcast_state(sds, rank, world, device)
+    ctx = Context(device)
+    eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision)
+    vae = build_vae_decoder(ctx, sds[1])
+    voc = build_hifigan(ctx, sds[2], hcfg.as_hparams())
+
+    B = args.batch
+    inp = clip_batch(B, T_LAT, L_CTX, clip0=rank * B, seed=SEED)
+    x0 = inp["x_latent"].to(device)
+    t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device)
+    midi, beats = inp["midi"].to(device), inp["beats"].to(device)
+    idx, dts = vm.euler_tables(args.flow_steps + 1)
+
+    def one_pass(k):
+        cond = eng.precompute_cond(t5, midi, beats, T_LAT)
+        z = eng.sample_cfg(x0, cond, idx, dts, args.scale, seed=SEED + k, clip_base=rank * B)
+        mel = vae.run(z)
+        return voc.run(mel)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    lib = L.load()
+
+    def read_prof(cls):
+        ms, fl, n, nt = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
+        L.check(lib.vb_prof_read(cls, C.byref(ms), C.byref(fl), C.byref(n), C.byref(nt)), "vb_prof_read")
+        return ms.value, fl.value, n.value, nt.value
+
+    # warmup; the last warmup pass times every kernel class to find the dominant one
+    dominant, breakdown = 2, {}
+    for w in range(max(args.warmup, 1)):
+        last = w == max(args.warmup, 1) - 1
+        if last:
+            L.check(lib.vb_prof_enable(7), "prof")
+        wav = one_pass(-1 - w)
+        torch.cuda.synchronize()
+        if last:
+            for cls in (0, 1, 2):
+                ms, fl, n, nt = read_prof(cls)
+                # launches beyond the event pool are extrapolated from the timed ones
+                breakdown[cls] = ms * (n / nt) if nt else 0.0
+            dominant = max(breakdown, key=breakdown.get)
+    assert torch.isfinite(wav).all()
+    L.check(lib.vb_prof_enable(1 << dominant), "prof")
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        wav = one_pass(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms, fl, n, nt = read_prof(dominant)
+    L.check(lib.vb_prof_enable(0), "prof")
+
+    if rank == 0:
+        bound, peak, kname = PEAK[dominant]
+        achieved = (fl * (nt / n) / (ms * 1e-3) / 1e12) if (ms > 0 and n > 0) else 0.0
+        total_mel_s = world * B * CLIP_SECONDS * args.steps
+        out = {
+            "metric": "mel-seconds generated/sec (20 s clip, %d flow steps)" % args.flow_steps,
+            "value": total_mel_s / elapsed,
+            "unit": "mel-s/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16 DiT (fp32 accumulate) + fp32 VAE/vocoder" if args.precision == "bf16" else "bf16x3 split DiT + fp32 VAE/vocoder",
+            "data": "synthetic (seeded PRNG clips, random-init checkpoints of the configured architecture)",
+            "config": {"workload": f"{B} x 20 s clips per GPU (T_lat=752, T_mel=1504, 24 kHz), {args.flow_steps} Euler steps x 2 NFE (CFG "
+                                   f"scale {args.scale}), Band-MoE E=4, VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml",
+                       "clips_per_gpu": B, "flow_steps": args.flow_steps, "precision": args.precision,
+                       "parallelism": f"batch-shard x{world}"},
+            "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "avg_launch_us": (1e3 * ms / nt) if nt else None, "launches_per_step": n / max(args.steps, 1),
+                         "class_ms_per_step_warmup": {PEAK[c][2]: round(v, 3) for c, v in breakdown.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sds_cpu[0], sds_cpu[1], sds_cpu[2], hcfg.as_hparams(), args.flow_steps,
+                                               args.cpu_flow_steps, args.scale)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

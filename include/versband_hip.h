@@ -1,0 +1,205 @@
+/* libversband_hip.so - C ABI of the MI355X-native AccompBand inference path.
+ *
+ * The reference (AaronZ345/VersBand) is pure Python with no native layer; these entry
+ * points are what a maintainer binds (ctypes) underneath the reference's
+ * own operator API.  Each entry cites the reference interface it replaces
+ * (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every tensor is a caller-owned, contiguous DEVICE pointer (torch `data_ptr()`);
+ *     nothing here allocates or frees device memory: scratch is passed in and its size is
+ *     queried with the matching *_workspace_bytes();
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as void*);
+ *   - return value: 0 = ok, <0 = VB_E_*; vb_last_error() returns a thread-local message;
+ *   - no exceptions cross the ABI; one host thread per context / GPU
+ *     (scripts/test_final.py:475 spawns one process per GPU).
+ *
+ * "planes" tensors are bf16 with np planes: plane 0 = round-to-nearest bf16 of the value,
+ * plane 1 (np == 2 only) = bf16 of the rounding residual, stored numel elements after
+ * plane 0.  np == 2 selects the split-precision ("bf16x3") MFMA path used for parity;
+ * np == 1 is the plain bf16 production path.
+ */
+#ifndef VERSBAND_HIP_H
+#define VERSBAND_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VB_OK 0
+#define VB_E_INVALID (-1)
+#define VB_E_HIP (-2)
+#define VB_E_STATE (-3)
+#define VB_MAX_DEPTH 16
+
+typedef struct vb_ctx vb_ctx;
+
+int vb_ctx_create(int device, vb_ctx** out);
+int vb_ctx_destroy(vb_ctx* ctx);
+const char* vb_last_error(void);
+int vb_abi_version(void);
+
+/* HIP-event timing of one kernel class inside a region (bench.py roofline): bit 0 = bf16 GEMM,
+ * bit 1 = attention, bit 2 = fp32 conv.  Events are recorded on the launch stream around every launch of
+ * the enabled classes; vb_prof_read synchronises the device and sums the elapsed times.
+ * flops = algorithmic FLOPs of the counted launches (2*M*N*K, 4*B*H*T*S*hd, 2*B*Co*Ci*k*T). */
+int vb_prof_enable(int class_mask);
+int vb_prof_read(int cls, double* ms_sum, double* flops, int64_t* launches, int64_t* timed);
+
+/* ---------------------------------------------------------------- DiT + Band-MoE ----
+ * TxtFlagLargeImprovedDiTV2 (ldm/modules/diffusionmodules/vocal2music_moe.py:293-520),
+ * constructor params of configs/vocal2music.yaml:36-43. */
+typedef struct {
+    int in_channels, hidden, heads, depth, num_experts, ffn_hidden, context_dim, ori_dim, max_len;
+    int np;            /* 1 = bf16, 2 = split precision (parity mode) */
+    float norm_eps;
+} vb_dit_config;
+
+typedef struct {
+    /* bf16 planes (np planes each, plane stride = numel) */
+    const void* wqkv;   /* [3D][D]  rows wq|wk|wv              flag_large_dit_moe.py:173-181 */
+    const void* wo;     /* [D][D]                               :193 */
+    const void* wq_m;   /* MoE.cross_attention in_proj rows 0:D vocal2music_moe.py:79 */
+    const void* wo_m;   /* MoE.cross_attention.out_proj */
+    const void* w13;    /* [2E][2H][D] routed experts, rows interleaved w1_0,w3_0,w1_1,...  (caption group first) */
+    const void* w2;     /* [2E][D][H] */
+    const void* w13f;   /* [E][2H][band]  band experts restricted to their channel band (:171-178) */
+    const void* w2f;    /* [E][band][H] */
+    const void* wky;    /* attention.wk_y [D][ctx]   (precompute only) */
+    const void* wvy;    /* attention.wv_y */
+    const void* wk_m;   /* MoE.cross_attention in_proj rows D:2D (precompute only) */
+    const void* wv_m;   /* rows 2D:3D */
+    /* fp32 */
+    const float* bq_m; const float* bo_m; const float* bk_m; const float* bv_m;
+    const float* attn_norm_w; const float* ffn_norm_w; const float* y_norm_w;
+    const float* cross_w;            /* tanh(attention.gate) [heads]   :401 */
+    const float* wcg; const float* bcg;   /* caption_gating_network  [E][D],[E] */
+    const float* wag; const float* bag;   /* acoustic_gating_network (precompute only) */
+} vb_dit_block_weights;
+
+typedef struct {
+    vb_dit_block_weights blocks[VB_MAX_DEPTH];
+    const float* t_freq_table;       /* [1000][256] sinusoid table (TimestepEmbedder.timestep_embedding) */
+    const float* t_mlp0_w; const float* t_mlp0_b; const float* t_mlp2_w; const float* t_mlp2_b;
+    const float* adaln_w; const float* adaln_b;   /* stacked [depth*6D + 2D][D]: blocks' adaLN then final_layer's */
+    const float* hl_w; const float* hl_b;         /* stacked high_level_gating_network [depth*2][D] */
+    const float* proj_in_w; const float* proj_in_b;  /* conv packed [5][C][D] */
+    const float* final_w; const float* final_b;      /* final_layer.linear [C][D] */
+    const float* rope_cos; const float* rope_sin;    /* [max_len][hd/2]  precompute_freqs_cis */
+    /* precompute only */
+    const float* midi_emb; const float* beats_emb;
+    const float* midi_conv_w; const float* midi_conv_b;    /* packed [5][D][D] */
+    const float* beats_conv_w; const float* beats_conv_b;
+    const float* final_proj_w; const float* final_proj_b;  /* packed [1][D][D] */
+    const void* c_emb0; const float* c_emb0_b;             /* planes(2) [D][ori] */
+    const void* c_emb2; const float* c_emb2_b;             /* planes(2) [D][D] */
+    const float* c_ln_w; const float* c_ln_b;
+    const float* cap_ln_w; const float* cap_ln_b;
+    const float* cap_lin_w; const float* cap_lin_b;
+} vb_dit_weights;
+
+/* replaces: model construction + load_state_dict (scripts/test_final.py:140-151).  The
+ * structs are copied; the device tensors they point to stay owned by the caller. */
+int vb_dit_load(vb_ctx* ctx, const vb_dit_config* cfg, const vb_dit_weights* w);
+
+size_t vb_dit_cond_bytes(const vb_dit_config* cfg, int B, int n_branch, int T, int L);
+size_t vb_dit_workspace_bytes(const vb_dit_config* cfg, int B, int n_branch, int T, int L);
+
+/* Everything of TxtFlagLargeDiT.forward that does not depend on (x,t): acoustic stem
+ * (vocal2music_moe.py:388-393), caption embedding + pooled embedding (:407-413), per block
+ * context K/V of Attention and MoE.cross_attention and the acoustic gate logits.
+ *   t5    f32 [n_branch*B][L][ori_dim]   (cond rows, then uncond rows)
+ *   midi, beats  int64 [B][T_mel]        (context['c_concat'], :384-385)
+ *   cond  caller buffer of vb_dit_cond_bytes() */
+int vb_dit_precompute_cond(vb_ctx* ctx, const float* t5, const int64_t* midi, const int64_t* beats, int B, int n_branch,
+                           int T, int T_mel, int L, void* cond, void* ws, void* stream);
+
+/* Injected Gumbel noise (parity path): g = -log(Exp(1)) draws, rows = n_branch*B*T tokens,
+ * per block: g1 [rows][2], g2 [rows][E], g3 [rows][E] (order of MoE.forward :134,150,151).
+ * Layout [depth][rows][w].  NULL => the engine draws its own (counter based, keyed by
+ * (seed, global clip, nfe, block, gate)). */
+typedef struct {
+    const float* g1; const float* g2; const float* g3;
+    uint64_t seed; int64_t clip_base; int nfe;
+} vb_noise;
+
+/* One network evaluation for the cond and uncond branches together:
+ * replaces the two apply_model() calls of Wrapper_cfg.forward (ldm/models/diffusion/cfm1_audio.py:158-159)
+ * -> DiffusionWrapper.forward (ddpm.py:1418-1436) -> TxtFlagLargeDiT.forward.
+ *   x      f32 [B][C][T]        (shared by both branches)
+ *   t_idx  int64 [n_branch*B]   integer diffusion index (cfm1_audio.py:156)
+ *   v_out  f32 [n_branch*B][C][T]
+ *   route_out  optional int32 [depth][2][rows] routed expert indices (caption, acoustic) */
+int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int B,
+                   int n_branch, int T, int L, float* v_out, int32_t* route_out, void* ws, void* stream);
+
+/* x += dt * (v_u + s (v_c - v_u))  - Wrapper_cfg.forward :160 + torchdyn fixed-step Euler */
+int vb_euler_cfg_step(float* x, const float* v, int B, int64_t per_item, float cfg_scale, float dt, int has_uncond, void* stream);
+
+/* CFMSampler.sample_cfg (ldm/models/diffusion/cfm1_audio_sampler.py:87-116): n_steps Euler steps.
+ *   t_idx_table int64[n_steps], dt_table f32[n_steps] : HOST arrays
+ *   noise: NULL or per-step injected noise laid out [step][depth][rows][w]
+ *   traj  optional f32 [n_steps+1][B][C][T] */
+int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps,
+                  const int64_t* t_idx_table, const float* dt_table, float cfg_scale, const vb_noise* noise, float* traj,
+                  void* ws, void* stream);
+
+/* ---------------------------------------------------- conv nets (VAE decoder, HiFi-GAN) ----
+ * AutoencoderKL.decode (ldm/models/autoencoder1d.py:55-58, Decoder1D :480-512) and
+ * HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) both run as a flat op
+ * list over fp32 [B][C][T] buffers; the list is built from the model config by the host side. */
+typedef struct { int channels; int tmul; int square; } vb_buf_desc;
+enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2 };
+enum { VB_ACT_NONE = 0, VB_ACT_LRELU = 1, VB_ACT_GN_SWISH = 2, VB_ACT_TANH = 3, VB_ACT_GN = 4 };
+#define VB_BUF_INPUT (-2)
+#define VB_BUF_OUTPUT (-3)
+typedef struct {
+    int kind;
+    int x, out, res, stats, w_buf;        /* buffer ids, -1 = none */
+    const float* w; const float* bias; const float* gn_gamma; const float* gn_beta;
+    int Ci, Co, ksize, dil, pad, upsample2, in_act, out_act, out_transposed, tr_stride, tr_pad, tr_k, gn_groups;
+    float in_slope, out_slope, alpha, beta, acc_scale;
+} vb_net_op;
+
+enum { VB_NET_VAE = 0, VB_NET_VOCODER = 1 };
+int vb_net_load(vb_ctx* ctx, int which, const vb_net_op* ops, int n_ops, const vb_buf_desc* bufs, int n_bufs, int in_channels,
+                int out_channels, int out_tmul);
+size_t vb_net_workspace_bytes(vb_ctx* ctx, int which, int B, int T);
+/* decode_first_stage (ldm/models/diffusion/ddpm_audio.py:379-392): z [B][C][T] -> mel [B][80][2T] */
+int vb_vae_decode(vb_ctx* ctx, const float* z, int B, int T, float* mel, void* ws, void* stream);
+/* HifiGAN.spec2wav (vocoder/hifigan/hifigan.py:20-30): mel [B][80][T] -> wav [B][T*hop] */
+int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream);
+
+/* ------------------------------------------------------------------- unit kernels ---- */
+/* RMSNorm (flag_large_dit_moe.py:52-77) * w then modulate (:80-81); shift/scale [B][mod_ld] or NULL */
+int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D,
+                        int T, float eps, void* out_planes, int np, void* stream);
+/* first argmax of logits + gumbel (hard Gumbel-softmax, vocal2music_moe.py:81-93) */
+int vb_router_top1(const float* logits, const float* gumbel, int N, int E, int32_t* idx, void* stream);
+/* stable bucketing of tokens by (caption, acoustic) expert: group_off int32[2E+1], perm int32[2N] */
+int vb_route_bucket(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, void* stream);
+/* generic GEMM  C[M][N] f32 = A[M][K] planes x B[N][K]^T planes (+bias) */
+int vb_gemm_bf16(const void* A, const void* Bw, const float* bias, int M, int N, int K, int np, float* C, void* stream);
+/* grouped SwiGLU expert FFN (FeedForward, flag_large_dit_moe.py:480-485) over routed buckets:
+ *   u planes [Ntok][D]; perm/group_off from vb_route_bucket (G groups); w13 [G][2H][D] interleaved, w2 [G][D][H];
+ *   out f32 [Ntok][D] = row_scale[tok] * FFN_g(u[tok]) written at perm order; hidden scratch planes [Nslots][H] */
+int vb_grouped_swiglu(const void* u, const int32_t* perm, const int32_t* group_off, int G, int n_slots, const void* w13,
+                      const void* w2, const float* row_scale, int D, int H, int np, void* hidden, float* out, void* stream);
+/* fused self (+cross) attention, head_dim 96 (Attention.forward, flag_large_dit_moe.py:381-402) */
+int vb_attention(const void* q, const void* k, const void* vt, const void* ky, const void* vyt, const float* cross_w, int B, int T,
+                 int Tpad, int L, int Lpad, int H, int hd, int np, void* out, void* stream);
+/* fp32 Conv1d / ConvTranspose1d on [B][C][T] (weights packed [phase][tap][Ci][Co]) */
+int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil, int pad,
+                  int tr_stride, int tr_pad, int tr_k, int T_out, int in_act, float in_slope, const float* res, float* out,
+                  void* stream);
+/* counter-based Gumbel draws: out[rows][w], rows = n_branch*B*T */
+int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
+                   void* stream);
+int vb_cast_planes(const float* x, int64_t n, void* out, int np, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

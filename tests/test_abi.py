@@ -1,0 +1,53 @@
+"""The C-ABI library loads and exports every symbol include/versband_hip.h declares (no compute, no GPU)."""
+import os
+import re
+
+from versband_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "versband_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vb_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    decl = _declared_symbols()
+    assert decl, "no declarations parsed"
+    assert sorted(L.PROTOTYPES) == decl, set(L.PROTOTYPES) ^ set(decl)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()                      # builds with hipcc if the in-tree .so is absent
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.vb_abi_version() == 1
+    assert lib.vb_last_error() is not None
+
+
+def test_struct_layouts_match_header_field_order():
+    src = open(os.path.join(ROOT, "include", "versband_hip.h")).read()
+    blk = re.search(r"typedef struct \{(.*?)\} vb_dit_block_weights;", src, flags=re.S).group(1)
+    blk = re.sub(r"/\*.*?\*/", "", blk, flags=re.S)
+    names = re.findall(r"\*\s*([a-z0-9_]+)\s*;", blk)
+    assert names == L.BLOCK_FIELDS
+    top = re.search(r"vb_dit_block_weights blocks\[VB_MAX_DEPTH\];(.*?)\} vb_dit_weights;", src, flags=re.S).group(1)
+    top = re.sub(r"/\*.*?\*/", "", top, flags=re.S)
+    assert re.findall(r"\*\s*([a-z0-9_]+)\s*;", top) == L.TOP_FIELDS
+    op = re.search(r"typedef struct \{\s*int kind;(.*?)\} vb_net_op;", src, flags=re.S).group(1)
+    op = re.sub(r"/\*.*?\*/", "", op, flags=re.S)
+    fields = ["kind"] + [n.strip().lstrip("*") for decl in re.findall(r"(?:int|const float\*|float)\s+([^;]+);", op)
+                         for n in decl.replace("const float*", "").split(",")]
+    assert fields == [f[0] for f in L.NetOp._fields_], fields
+
+
+def test_no_gpu_means_loud_failure():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from versband_amd.engine import Context
+    with pytest.raises(L.VersbandError):
+        Context("cuda:0")

@@ -1,0 +1,232 @@
+"""Unit parity of every HIP kernel behind the C ABI vs the CPU oracle (float64 where cheap).
+Integer/index results are bit-exact; float tolerances are written next to each check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+from tests.helpers import describe, rel_l2
+from versband_amd import _lib as L
+from versband_amd import pack, prng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return L.load()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rnd(shape, name, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy(prng.normal(prng.key_seed(7, name), n).reshape(shape)) * scale
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- GEMM ------
+@pytest.mark.parametrize("M,N,K", [(200, 132, 96), (1504, 768, 768), (129, 2304, 768), (77, 64, 1024), (300, 192, 512)])
+@pytest.mark.parametrize("npl", [1, 2])
+def test_gemm_bf16(lib, M, N, K, npl):
+    A, B, bias = rnd((M, K), "gA"), rnd((N, K), "gB", 0.05), rnd((N,), "gbias")
+    Ap, Bp = dev(pack.to_planes(A, npl)), dev(pack.to_planes(B, npl))
+    Cd = torch.full((M, N), float("nan"), device="cuda")
+    L.check(lib.vb_gemm_bf16(L.ptr(Ap), L.ptr(Bp), L.ptr(dev(bias)), M, N, K, npl, L.ptr(Cd), L.stream_ptr()), "gemm")
+    sync()
+    if npl == 1:   # exact products of the bf16-rounded operands, fp32 accumulate
+        ref = Ap[0].float().double().cpu() @ Bp[0].float().double().cpu().T + bias.double()
+        tol = 2e-6
+    else:          # split precision: fp32-class
+        ref = A.double() @ B.double().T + bias.double()
+        tol = 3e-5
+    assert rel_l2(Cd, ref) < tol, describe(f"gemm {M}x{N}x{K} np={npl}", Cd, ref)
+
+
+# ---------------------------------------------------------------- conv ------
+CONV_CASES = [  # B, Ci, T, Co, k, dil, in_act, res
+    (2, 20, 50, 1536, 5, 1, 0, False),
+    (1, 32, 300, 32, 11, 5, 1, True),
+    (2, 80, 37, 80, 3, 1, 0, False),
+    (1, 64, 200, 64, 7, 3, 1, True),
+    (1, 32, 500, 1, 7, 1, 1, False),
+    (2, 1536, 40, 768, 3, 1, 0, False),
+    (1, 256, 130, 256, 3, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize("B,Ci,T,Co,k,dil,act,res", CONV_CASES)
+def test_conv1d_f32(lib, B, Ci, T, Co, k, dil, act, res):
+    x, w, b = rnd((B, Ci, T), "cx"), rnd((Co, Ci, k), "cw", 1.0 / (Ci * k) ** 0.5), rnd((Co,), "cb")
+    r = rnd((B, Co, T), "cr") if res else None
+    pad = (k - 1) * dil // 2
+    out = torch.full((B, Co, T), float("nan"), device="cuda")
+    L.check(lib.vb_conv1d_f32(L.ptr(dev(x)), L.ptr(dev(pack.pack_conv(w))), L.ptr(dev(b)), B, Ci, T, Co, k, dil, pad, 1, 0, 0, T,
+                              act, 0.1, L.ptr(dev(r)) if res else None, L.ptr(out), L.stream_ptr()), "conv")
+    sync()
+    xin = F.leaky_relu(x.double(), 0.1) if act else x.double()
+    ref = F.conv1d(xin, w.double(), b.double(), dilation=dil, padding=pad)
+    if res:
+        ref = ref + r.double()
+    assert rel_l2(out, ref) < 2e-6, describe("conv1d", out, ref)   # exact-fp32 MFMA: fp32 roundoff only
+
+
+@pytest.mark.parametrize("B,Ci,T,Co,k,u", [(2, 512, 24, 256, 16, 8), (1, 256, 33, 128, 15, 5), (1, 128, 20, 64, 11, 5),
+                                          (2, 64, 50, 32, 4, 2), (1, 128, 19, 64, 8, 4)])
+def test_conv_transpose1d_f32(lib, B, Ci, T, Co, k, u):
+    x, w, b = rnd((B, Ci, T), "tx"), rnd((Ci, Co, k), "tw", (u / (Ci * k)) ** 0.5), rnd((Co,), "tb")
+    p = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=p)
+    T_out = ref.shape[-1]
+    out = torch.full((B, Co, T_out), float("nan"), device="cuda")
+    L.check(lib.vb_conv1d_f32(L.ptr(dev(x)), L.ptr(dev(pack.pack_conv_transpose(w, u))), L.ptr(dev(b)), B, Ci, T, Co, 0, 1, 0, u, p,
+                              k, T_out, 1, 0.1, None, L.ptr(out), L.stream_ptr()), "convT")
+    sync()
+    assert rel_l2(out, ref) < 2e-6, describe("conv_transpose1d", out, ref)
+
+
+# ---------------------------------------------------------------- attention ------
+@pytest.mark.parametrize("B,T,Lc,H,cross,self_", [(2, 200, 80, 8, True, True), (1, 64, 80, 2, True, False), (1, 752, 80, 1, True, True),
+                                                 (2, 130, 16, 3, False, True)])
+@pytest.mark.parametrize("npl", [1, 2])
+def test_attention(lib, B, T, Lc, H, cross, self_, npl):
+    hd = 96
+    q, k, v = rnd((B, T, H, hd), "aq"), rnd((B, T, H, hd), "ak"), rnd((B, T, H, hd), "av")
+    ky, vy = rnd((B, Lc, H, hd), "aky"), rnd((B, Lc, H, hd), "avy")
+    cw = rnd((H,), "acw")
+    Tpad, Lpad = (T + 63) // 64 * 64, (Lc + 63) // 64 * 64
+
+    def vt_layout(x, S, Spad):   # [B,S,H,hd] -> [B,H,hd,Spad] zero padded
+        o = torch.zeros(B, H, hd, Spad)
+        o[..., :S] = x.permute(0, 2, 3, 1)
+        return o
+    qp, kp, vtp = dev(pack.to_planes(q, npl)), dev(pack.to_planes(k, npl)), dev(pack.to_planes(vt_layout(v, T, Tpad), npl))
+    kyp, vytp = dev(pack.to_planes(ky, npl)), dev(pack.to_planes(vt_layout(vy, Lc, Lpad), npl))
+    out = torch.zeros(npl, B, T, H, hd, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.vb_attention(L.ptr(qp), L.ptr(kp) if self_ else None, L.ptr(vtp) if self_ else None, L.ptr(kyp) if cross else None,
+                             L.ptr(vytp) if cross else None, L.ptr(dev(cw)) if cross else None, B, T, Tpad, Lc, Lpad, H, hd, npl,
+                             L.ptr(out), L.stream_ptr()), "attention")
+    sync()
+    got = pack.planes_to_float(out.cpu())
+    src = (lambda t, pl: pack.planes_to_float(pl.cpu()).reshape(t.shape)) if npl == 1 else (lambda t, pl: t)
+    qq, kk = src(q, qp).double(), src(k, kp).double()
+    vv = v.to(torch.bfloat16).double() if npl == 1 else v.double()
+    kyy, vyy = src(ky, kyp).double(), (vy.to(torch.bfloat16).double() if npl == 1 else vy.double())
+    ref = torch.zeros(B, H, T, hd, dtype=torch.float64)
+    if self_:
+        ref = ref + ref_cpu.sdpa(qq.permute(0, 2, 1, 3), kk.permute(0, 2, 1, 3), vv.permute(0, 2, 1, 3))
+    if cross:
+        ref = ref + ref_cpu.sdpa(qq.permute(0, 2, 1, 3), kyy.permute(0, 2, 1, 3), vyy.permute(0, 2, 1, 3)) * cw.double().view(1, H, 1, 1)
+    ref = ref.permute(0, 2, 1, 3)
+    # np=1: P and the output are rounded to bf16 (2^-9 relative each); np=2: fp32-class
+    tol = 6e-3 if npl == 1 else 4e-5
+    assert rel_l2(got, ref) < tol, describe(f"attention np={npl}", got, ref)
+
+
+# ---------------------------------------------------------------- small kernels ------
+@pytest.mark.parametrize("npl", [1, 2])
+def test_rmsnorm_modulate(lib, npl):
+    B, T, D = 3, 37, 768
+    h, w = rnd((B * T, D), "rh", 2.0), rnd((D,), "rw") * 0.2 + 1
+    mod = rnd((B, 6 * D), "rmod", 0.3)
+    out = torch.zeros(npl, B * T, D, dtype=torch.bfloat16, device="cuda")
+    md = dev(mod)
+    L.check(lib.vb_rmsnorm_modulate(L.ptr(dev(h)), L.ptr(dev(w)), C.c_void_p(md.data_ptr()), C.c_void_p(md.data_ptr() + 4 * D), 6 * D,
+                                    B * T, D, T, 1e-5, L.ptr(out), npl, L.stream_ptr()), "rmsnorm")
+    sync()
+    ref = ref_cpu.modulate(ref_cpu.rmsnorm(h.view(B, T, D), w, 1e-5), mod[:, :D], mod[:, D:2 * D]).reshape(B * T, D)
+    got = pack.planes_to_float(out.cpu())
+    tol = 4e-3 if npl == 1 else 2e-5
+    assert rel_l2(got, ref) < tol, describe("rmsnorm_modulate", got, ref)
+
+
+@pytest.mark.parametrize("E", [4, 8])
+def test_router_top1_bit_exact(lib, E):
+    N = 5000
+    logits, gum = rnd((N, E), "rl"), ref_cpu.gumbel_from_exponential(torch.from_numpy(prng.exponential(11, N * E).reshape(N, E)))
+    logits[:50] = torch.round(logits[:50])         # force exact ties: the first maximum must win
+    gum[:50] = 0.0
+    idx = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.vb_router_top1(L.ptr(dev(logits)), L.ptr(dev(gum)), N, E, L.ptr(idx), L.stream_ptr()), "router_top1")
+    sync()
+    ref, _ = ref_cpu.router_top1(logits, gum, 2.0)
+    assert torch.equal(idx.cpu().long(), ref), f"{int((idx.cpu().long() != ref).sum())} of {N} routing indices differ"
+
+
+@pytest.mark.parametrize("N,E", [(1, 4), (1000, 4), (12032, 4), (3000, 8)])
+def test_route_bucket(lib, N, E):
+    ic = torch.from_numpy(prng.randint(3, N, 0, E)).int()
+    ia = torch.from_numpy(prng.randint(4, N, 0, E)).int()
+    if N > 100:
+        ic[ic == 2] = 1                                # an empty group
+    off = torch.full((2 * E + 1,), -1, dtype=torch.int32, device="cuda")
+    perm = torch.full((2 * N,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.vb_route_bucket(L.ptr(dev(ic)), L.ptr(dev(ia)), N, E, L.ptr(off), L.ptr(perm), L.stream_ptr()), "bucket")
+    sync()
+    off, perm = off.cpu(), perm.cpu()
+    cnt = torch.cat([torch.bincount(ic.long(), minlength=E), torch.bincount(ia.long(), minlength=E)])
+    assert torch.equal(off, torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]).int())
+    for g in range(2 * E):
+        sel = perm[off[g]:off[g + 1]].long()
+        src = ic if g < E else ia
+        want = (src == (g % E)).nonzero().squeeze(1)
+        assert torch.equal(sel, want), f"group {g}: stable order violated"      # stable: tokens in ascending order
+
+
+@pytest.mark.parametrize("npl", [1, 2])
+def test_grouped_swiglu(lib, npl):
+    N, D, H, G = 700, 768, 512, 4
+    u = rnd((N, D), "su")
+    w1, w3, w2 = rnd((G, H, D), "sw1", 0.04), rnd((G, H, D), "sw3", 0.04), rnd((G, D, H), "sw2", 0.04)
+    idx = torch.from_numpy(prng.randint(5, N, 0, G)).int()
+    scale = rnd((N,), "ss").abs() + 0.1
+    off = torch.zeros(2 * G + 1, dtype=torch.int32, device="cuda")
+    perm = torch.zeros(2 * N, dtype=torch.int32, device="cuda")
+    L.check(lib.vb_route_bucket(L.ptr(dev(idx)), L.ptr(dev(idx)), N, G, L.ptr(off), L.ptr(perm), L.stream_ptr()), "bucket")
+    w13 = torch.stack([w1, w3], dim=2).reshape(G, 2 * H, D)
+    up, w13p, w2p = dev(pack.to_planes(u, npl)), dev(pack.to_planes(w13, npl)), dev(pack.to_planes(w2, npl))
+    hidden = torch.zeros(npl, N, H, dtype=torch.bfloat16, device="cuda")
+    out = torch.full((N, D), float("nan"), device="cuda")
+    L.check(lib.vb_grouped_swiglu(L.ptr(up), L.ptr(perm), L.ptr(off), G, N, L.ptr(w13p), L.ptr(w2p), L.ptr(dev(scale)), D, H, npl,
+                                  L.ptr(hidden), L.ptr(out), L.stream_ptr()), "grouped_swiglu")
+    sync()
+    ref = torch.zeros(N, D, dtype=torch.float64)
+    for g in range(G):
+        sel = (idx == g).nonzero().squeeze(1)
+        ref[sel] = ref_cpu.swiglu(u[sel].double(), w1[g].double(), w2[g].double(), w3[g].double()) * scale[sel].double().unsqueeze(1)
+    tol = 8e-3 if npl == 1 else 4e-5
+    assert rel_l2(out, ref) < tol, describe(f"grouped_swiglu np={npl}", out, ref)
+
+
+def test_fill_gumbel_statistics_and_keying(lib):
+    B, nb, T, W = 2, 2, 500, 4
+    n = nb * B * T * W
+    a = torch.zeros(n, device="cuda")
+    b = torch.zeros(n, device="cuda")
+    L.check(lib.vb_fill_gumbel(L.ptr(a), B, nb, T, W, 99, 0, 3, 1, 2, L.stream_ptr()), "fill_gumbel")
+    L.check(lib.vb_fill_gumbel(L.ptr(b), 1, nb, T, W, 99, 1, 3, 1, 2, L.stream_ptr()), "fill_gumbel")   # clip 1 alone
+    sync()
+    a = a.cpu().view(nb, B, T, W)
+    assert abs(float(a.mean()) - 0.5772) < 0.05 and abs(float(a.var()) - 1.6449) < 0.15
+    assert torch.isfinite(a).all()
+    # draws are keyed by the GLOBAL clip index: clip 1 gets the same numbers wherever it sits in a batch
+    assert torch.equal(a[:, 1], b.cpu().view(nb, 1, T, W)[:, 0])
+    assert not torch.equal(a[:, 0], a[:, 1])
+
+
+def test_cast_planes_roundtrip(lib):
+    x = rnd((1000, 33), "cp", 3.0)
+    out = torch.zeros(2, 1000, 33, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.vb_cast_planes(L.ptr(dev(x)), x.numel(), L.ptr(out), 2, L.stream_ptr()), "cast")
+    sync()
+    assert torch.equal(out.cpu(), pack.to_planes(x, 2))       # bit-exact with the host packer (RNE both sides)
+    assert rel_l2(pack.planes_to_float(out.cpu()), x) < 2e-5

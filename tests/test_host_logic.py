@@ -1,0 +1,134 @@
+"""CPU tests of the host logic: packing layouts, Euler/t-index tables, factory + checkpoint plumbing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+from versband_amd import model as vm
+from versband_amd import pack, prng, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_prng_is_stable():
+    # exact values: the uniform pipeline is integer arithmetic and must never drift across machines
+    u = prng.uniform(prng.key_seed(1234, "x"), 4)
+    assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
+    assert prng.bits64(1, 2).tolist() == [10451216379200822465, 13757245211066428519]
+    e = prng.exponential(5, 1000)
+    assert (e > 0).all() and abs(float(e.mean()) - 1.0) < 0.1
+
+
+def test_planes_split_is_fp32_class():
+    w = torch.from_numpy(prng.normal(3, 4096)).reshape(64, 64)
+    p2 = pack.to_planes(w, 2)
+    assert p2.dtype == torch.bfloat16 and p2.shape == (2, 64, 64)
+    assert float((pack.planes_to_float(p2) - w).abs().max() / w.abs().max()) < 2 ** -15
+    assert torch.equal(pack.to_planes(w, 1)[0], p2[0])
+
+
+def test_conv_transpose_polyphase_packing_matches_conv_transpose():
+    for (ci, co, k, u) in [(3, 2, 16, 8), (2, 3, 15, 5), (2, 2, 11, 5), (1, 1, 4, 2)]:
+        w = torch.from_numpy(prng.normal(9, ci * co * k).reshape(ci, co, k)).double()
+        x = torch.from_numpy(prng.normal(10, ci * 13).reshape(1, ci, 13)).double()
+        p = (k - u) // 2
+        ref = F.conv_transpose1d(x, w, stride=u, padding=p)
+        wp = pack.pack_conv_transpose(w.float(), u).double()
+        kmax = wp.shape[1]
+        out = torch.zeros_like(ref)
+        T_out = ref.shape[-1]
+        for ph in range(u):                     # restates the kernel's polyphase index arithmetic
+            d = p - ph
+            q0 = (d + u - 1) // u if d > 0 else 0
+            in_off, out_off = q0 - (kmax - 1), q0 * u + ph - p
+            n = 0
+            while n * u + out_off < T_out:
+                acc = torch.zeros(co, dtype=torch.float64)
+                for j in range(kmax):
+                    idx = n + in_off + j
+                    if 0 <= idx < x.shape[-1]:
+                        acc += wp[ph, j].T @ x[0, :, idx]
+                out[0, :, n * u + out_off] = acc
+                n += 1
+        assert torch.allclose(out, ref, atol=1e-12), (ci, co, k, u)
+
+
+def test_euler_tables_match_oracle_and_quirk():
+    for n in (10, 24, 50):
+        idx, dts = vm.euler_tables(n + 1)
+        _, ref = ref_cpu.t_index_table(n + 1)
+        assert idx == ref and len(dts) == n
+        assert abs(sum(dts) - 1.0) < 1e-5
+    idx, _ = vm.euler_tables(51)
+    assert idx[5] == 99 and idx[9] == 179             # float32 truncation quirk
+    idx, dts = vm.euler_tables(25, t_start=20)
+    assert len(idx) == 4
+
+
+def test_pack_dit_layouts():
+    cfg = synth.DiTConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(cfg), 1)
+    pk = pack.pack_dit(sd, cfg, 2, "cpu")
+    b0 = pk["blocks"][0]
+    D, H, E = cfg.hidden_size, cfg.ffn_hidden, cfg.num_experts
+    assert b0["wqkv"].shape == (2, 3 * D, D) and b0["w13"].shape == (2, 2 * E, 2 * H, D) and b0["w2"].shape == (2, 2 * E, D, H)
+    assert b0["w13f"].shape == (2, E, 2 * H, D // E) and b0["w2f"].shape == (2, E, D // E, H)
+    w13 = pack.planes_to_float(b0["w13"])
+    assert torch.allclose(w13[1, 0::2], sd["blocks.0.feed_forward.caption_experts.1.w1.weight"], atol=1e-6)
+    assert torch.allclose(w13[E + 2, 1::2], sd["blocks.0.feed_forward.acoustic_experts.2.w3.weight"], atol=1e-6)
+    w2f = pack.planes_to_float(b0["w2f"])
+    band = D // E
+    assert torch.allclose(w2f[3], sd["blocks.0.feed_forward.freq_experts.3.w2.weight"][3 * band:4 * band], atol=1e-6)
+    assert pk["top"]["adaln_w"].shape == (cfg.depth * 6 * D + 2 * D, D)
+    assert torch.equal(pk["top"]["t_freq_table"][416], ref_cpu.timestep_embedding(torch.tensor([416]))[0])
+    assert torch.allclose(b0["cross_w"], torch.tanh(sd["blocks.0.attention.gate"]))
+
+
+def test_factory_and_checkpoint_plumbing(tmp_path):
+    cfg = vm.load_config(os.path.join(ROOT, "configs", "vocal2music.yaml"))
+    m = vm.instantiate_from_config(cfg.model)
+    assert type(m).__name__ == "CFM" and m.first_stage_model.embed_dim == 20 and m.num_timesteps == 1000
+    assert m.model.diffusion_model.cfg.ffn_hidden == 512
+    with pytest.raises(KeyError):
+        vm.instantiate_from_config({"params": {}})
+    sd = {"model.diffusion_model." + k: v for k, v in synth.make_state_dict(synth.dit_shapes(synth.DiTConfig()), 1).items()}
+    sd["scale_factor"] = torch.tensor(0.5)
+    sd["betas"] = torch.zeros(1000)                        # DDPM buffers are ignored like strict=False does
+    m.load_state_dict(sd, strict=False)
+    assert float(m.scale_factor) == 0.5 and "proj_in.weight" in m._dit_state
+    s = vm.CFMSampler(m, num_timesteps=1000)
+    assert s._shape([20, 752], 8) == (8, 20, 752)
+    assert s._shape(None, 2) == (2, 20, 750)
+    # get_learned_conditioning passes pre-computed T5 embeddings through and keeps the acoustic dict
+    c = m.get_learned_conditioning({"caption": torch.zeros(2, 80, 1024), "acoustic": {"midi": 1}, "name": ["a", "b"]})
+    assert c["caption"].shape == (2, 80, 1024) and c["acoustic"] == {"midi": 1}
+    c = m.get_learned_conditioning({"caption": ["Style: pop", ""], "acoustic": {}, "name": ["a", "b"]})
+    assert c["caption"].shape == (2, 80, 1024)
+
+
+def test_vocoder_checkpoint_discovery(tmp_path):
+    import yaml
+    hcfg = synth.HifiGanConfig()
+    base = tmp_path / "base.yaml"
+    yaml.safe_dump({"resblock": "2", "upsample_initial_channel": 512}, open(base, "w"))
+    hp = hcfg.as_hparams()
+    hp["base_config"] = "./base.yaml"
+    yaml.safe_dump(hp, open(tmp_path / "config.yaml", "w"))
+    got = vm.set_hparams(str(tmp_path / "config.yaml"))
+    assert got["resblock"] == "1" and got["upsample_rates"] == [8, 5, 4, 2]        # child overrides base
+    torch.save({"state_dict": {"model_gen.conv_pre.bias": torch.ones(3), "model_disc.x": torch.ones(1)}},
+               tmp_path / "model_ckpt_steps_20.ckpt")
+    torch.save({"state_dict": {"model_gen.conv_pre.bias": torch.zeros(3)}}, tmp_path / "model_ckpt_steps_3.ckpt")
+    sd = vm.load_ckpt_state(str(tmp_path))
+    assert list(sd) == ["conv_pre.bias"] and float(sd["conv_pre.bias"].sum()) == 3.0
+
+
+def test_synthetic_inputs_respect_embedding_ranges():
+    c = synth.make_clip_inputs(1234, 3, 752)
+    assert c["midi"].shape == (1, 1504) and int(c["midi"].max()) <= 128 and int(c["beats"].max()) <= 2
+    assert int(c["midi"][0, -1]) == 128 and int(c["beats"][0, -1]) == 2               # pad values
+    a, b = synth.make_clip_inputs(1234, 3, 16), synth.make_clip_inputs(1234, 4, 16)
+    assert not torch.equal(a["x_latent"], b["x_latent"])

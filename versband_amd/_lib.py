@@ -1,0 +1,137 @@
+"""ctypes binding of libversband_hip.so (include/versband_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call
+fails, an exception is raised.  ``load()`` builds the library with hipcc when
+the in-tree .so is absent (hipcc cross-compiles gfx950 without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libversband_hip.so")
+VB_MAX_DEPTH = 16
+
+c_void_p, c_int, c_float, c_i64, c_u64, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64, C.c_size_t
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, c_int) for n in ("in_channels", "hidden", "heads", "depth", "num_experts", "ffn_hidden", "context_dim",
+                                      "ori_dim", "max_len", "np")] + [("norm_eps", c_float)]
+
+
+BLOCK_FIELDS = ["wqkv", "wo", "wq_m", "wo_m", "w13", "w2", "w13f", "w2f", "wky", "wvy", "wk_m", "wv_m",
+                "bq_m", "bo_m", "bk_m", "bv_m", "attn_norm_w", "ffn_norm_w", "y_norm_w", "cross_w", "wcg", "bcg", "wag", "bag"]
+
+
+class DitBlockWeights(C.Structure):
+    _fields_ = [(n, c_void_p) for n in BLOCK_FIELDS]
+
+
+TOP_FIELDS = ["t_freq_table", "t_mlp0_w", "t_mlp0_b", "t_mlp2_w", "t_mlp2_b", "adaln_w", "adaln_b", "hl_w", "hl_b",
+              "proj_in_w", "proj_in_b", "final_w", "final_b", "rope_cos", "rope_sin", "midi_emb", "beats_emb",
+              "midi_conv_w", "midi_conv_b", "beats_conv_w", "beats_conv_b", "final_proj_w", "final_proj_b",
+              "c_emb0", "c_emb0_b", "c_emb2", "c_emb2_b", "c_ln_w", "c_ln_b", "cap_ln_w", "cap_ln_b", "cap_lin_w", "cap_lin_b"]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [("blocks", DitBlockWeights * VB_MAX_DEPTH)] + [(n, c_void_p) for n in TOP_FIELDS]
+
+
+class Noise(C.Structure):
+    _fields_ = [("g1", c_void_p), ("g2", c_void_p), ("g3", c_void_p), ("seed", c_u64), ("clip_base", c_i64), ("nfe", c_int)]
+
+
+class BufDesc(C.Structure):
+    _fields_ = [("channels", c_int), ("tmul", c_int), ("square", c_int)]
+
+
+class NetOp(C.Structure):
+    _fields_ = ([("kind", c_int)] + [(n, c_int) for n in ("x", "out", "res", "stats", "w_buf")]
+                + [(n, c_void_p) for n in ("w", "bias", "gn_gamma", "gn_beta")]
+                + [(n, c_int) for n in ("Ci", "Co", "ksize", "dil", "pad", "upsample2", "in_act", "out_act", "out_transposed",
+                                        "tr_stride", "tr_pad", "tr_k", "gn_groups")]
+                + [(n, c_float) for n in ("in_slope", "out_slope", "alpha", "beta", "acc_scale")])
+
+
+OP_CONV, OP_GN_STATS, OP_SOFTMAX_T = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_GN_SWISH, ACT_TANH, ACT_GN = 0, 1, 2, 3, 4
+BUF_INPUT, BUF_OUTPUT = -2, -3
+NET_VAE, NET_VOCODER = 0, 1
+
+# name -> (restype, argtypes); the list doubles as the export check of tests/test_abi.py
+P = c_void_p
+PROTOTYPES = {
+    "vb_ctx_create": (c_int, [c_int, C.POINTER(P)]),
+    "vb_ctx_destroy": (c_int, [P]),
+    "vb_last_error": (C.c_char_p, []),
+    "vb_abi_version": (c_int, []),
+    "vb_prof_enable": (c_int, [c_int]),
+    "vb_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "vb_dit_load": (c_int, [P, C.POINTER(DitConfig), C.POINTER(DitWeights)]),
+    "vb_dit_cond_bytes": (c_size_t, [C.POINTER(DitConfig), c_int, c_int, c_int, c_int]),
+    "vb_dit_workspace_bytes": (c_size_t, [C.POINTER(DitConfig), c_int, c_int, c_int, c_int]),
+    "vb_dit_precompute_cond": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "vb_dit_forward": (c_int, [P, P, P, P, C.POINTER(Noise), c_int, c_int, c_int, c_int, P, P, P, P]),
+    "vb_euler_cfg_step": (c_int, [P, P, c_int, c_i64, c_float, c_float, c_int, P]),
+    "vb_sample_cfg": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, C.POINTER(Noise), P, P, P]),
+    "vb_net_load": (c_int, [P, c_int, C.POINTER(NetOp), c_int, C.POINTER(BufDesc), c_int, c_int, c_int, c_int]),
+    "vb_net_workspace_bytes": (c_size_t, [P, c_int, c_int, c_int]),
+    "vb_vae_decode": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_hifigan_forward": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_rmsnorm_modulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, P]),
+    "vb_router_top1": (c_int, [P, P, c_int, c_int, P, P]),
+    "vb_route_bucket": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_gemm_bf16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "vb_grouped_swiglu": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "vb_attention": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "vb_conv1d_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                              c_float, P, P, P]),
+    "vb_fill_gumbel": (c_int, [P, c_int, c_int, c_int, c_int, c_u64, c_i64, c_int, c_int, c_int, P]),
+    "vb_cast_planes": (c_int, [P, c_i64, P, c_int, P]),
+}
+
+_lib = None
+
+
+class VersbandError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True):
+    """dlopen the in-tree library (build it first if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
+        from .build import build
+        build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().vb_last_error()
+        raise VersbandError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "non-contiguous tensor handed to the C ABI"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

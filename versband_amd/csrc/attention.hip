@@ -1,0 +1,235 @@
+// Flash attention for the DiT blocks (gfx950, head_dim 96, bf16 planes, fp32 softmax).
+//
+//   out = softmax(q k^T * s) v            (self, T keys)
+//       + w[h] * softmax(q ky^T * s) vy   (cross, L keys; two SEPARATE softmaxes,
+//                                           flag_large_dit_moe.py:381-402)
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32
+// query rows.  K tiles (64 keys) and V^T tiles live in LDS and are shared by the 4
+// waves.  S is computed TRANSPOSED (S^T = K Q^T, mfma(A=K, B=Q)) so a lane owns one
+// query column: the row max / row sum are 32 in-register values + one exchange with
+// lane^32.  For P V the MFMA k-slot order is free as long as A and B agree, so each
+// lane feeds its own 8 P registers as the B operand and reads the matching keys of
+// V^T (stored d-major by the QKV GEMM epilogue) with two 8-byte LDS reads - no
+// cross-lane shuffle of P at all.
+// SPLIT = bf16x3 parity mode (hi*hi + lo*hi + hi*lo for both Q K^T and P V).
+#include "kernels.h"
+
+#define HD 96
+#define KT 64                 // keys per tile
+#define KPITCH 104            // bf16 elements per K row in LDS (208 B: 13 x 16 B -> conflict-free b128 reads)
+#define VPITCH 68             // bf16 elements per V^T row in LDS (136 B -> conflict-free b64 reads)
+
+struct AttnDev {
+    const bf16_t* q; int64_t q_plane;
+    const bf16_t* k; int64_t k_plane;
+    const bf16_t* vt; int64_t vt_plane;
+    const bf16_t* ky; int64_t ky_plane;
+    const bf16_t* vyt; int64_t vyt_plane;
+    const float* cross_w;
+    bf16_t* out; int64_t out_plane; int out_np;
+    int B, T, Tpad, L, Lpad, H, D;
+    int has_self, has_cross, kv_batch_mod;
+    float scale_log2e;
+};
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
+    constexpr int NP = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) bf16_t Kl[NP][KT * KPITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t Vl[NP][HD * VPITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, ql = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = q0 + ql;
+    const int qrow_c = qrow < p.T ? qrow : p.T - 1;
+
+    // ---- Q fragments (B operand): Q[q = ql][d = ks*16 + g*8 .. +8]
+    bf16x8 qf[6], qlf[6];
+    {
+        const bf16_t* qp = p.q + ((int64_t)b * p.T + qrow_c) * p.D + h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+            if constexpr (SPLIT) qlf[ks] = *reinterpret_cast<const bf16x8*>(qp + p.q_plane + ks * 16);
+        }
+    }
+
+    f32x16 o[3], oc[3];
+    float res_l = 1.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[i][r] = 0.f; oc[i][r] = 0.f; }
+
+    auto kv_pass = [&](const bf16_t* Kg, int64_t kplane, const bf16_t* Vg, int64_t vplane, int nkeys, int vpad, int kb_batch,
+                       f32x16 (&acc)[3], float& l_out) __attribute__((always_inline)) {
+        float m_run = -1e30f, l_run = 0.f;
+        const int ntiles = (nkeys + KT - 1) / KT;
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int key0 = kt * KT;
+            __syncthreads();
+            // ---- stage K tile [64 keys][96] and V^T tile [96][64 keys]
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                int id = tid + i * 256;
+                int key = id / 12, c = id - key * 12;
+                bool ok = (key0 + key) < nkeys;
+                const bf16_t* src = Kg + ((int64_t)kb_batch * nkeys + (ok ? key0 + key : 0)) * p.D + h * HD + c * 8;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    uint4 v = ok ? *reinterpret_cast<const uint4*>(src + pl * kplane) : make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(&Kl[pl][key * KPITCH + c * 8]) = v;
+                }
+                int d = id >> 3, c2 = id & 7;
+                const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + d) * vpad + key0 + c2 * 8;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    uint4 v = *reinterpret_cast<const uint4*>(vs + pl * vplane);
+                    uint2* dst = reinterpret_cast<uint2*>(&Vl[pl][d * VPITCH + c2 * 8]);
+                    dst[0] = make_uint2(v.x, v.y);
+                    dst[1] = make_uint2(v.z, v.w);
+                }
+            }
+            __syncthreads();
+            // ---- S^T = K Q^T  (two 32-key sub-tiles)
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    const int off = (kb * 32 + ql) * KPITCH + ks * 16 + g * 8;
+                    bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kl[0][off]);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                    if constexpr (SPLIT) {
+                        bf16x8 klo = *reinterpret_cast<const bf16x8*>(&Kl[1][off]);
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[ks], s[kb], 0, 0, 0);
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qlf[ks], s[kb], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- online softmax (base-2 domain)
+            float tmax = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    float v = (key < nkeys) ? s[kb][r] * p.scale_log2e : -1e30f;
+                    s[kb][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float e = exp2f(s[kb][r] - m_new);
+                    s[kb][r] = e;
+                    psum += e;
+                }
+            l_run += psum;
+            // ---- O^T += V^T P^T   (k-slot e of lane group g <-> key base + 8*(e>>2) + 4g + (e&3))
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    bf16x8 ph, pl_;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float pv = s[kb][hs * 8 + e];
+                        ph[e] = f2bf(pv);
+                        if constexpr (SPLIT) pl_[e] = f2bf(pv - bf2f(ph[e]));
+                    }
+                    const int kbase = kb * 32 + hs * 16 + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 3; ++dt) {
+                        const int voff = (dt * 32 + ql) * VPITCH + kbase;
+                        bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&Vl[0][voff]);
+                        bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&Vl[0][voff + 8]);
+                        bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, acc[dt], 0, 0, 0);
+                        if constexpr (SPLIT) {
+                            bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&Vl[1][voff]);
+                            bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&Vl[1][voff + 8]);
+                            bf16x8 vlo = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vlo, ph, acc[dt], 0, 0, 0);
+                            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pl_, acc[dt], 0, 0, 0);
+                        }
+                    }
+                }
+        }
+        l_out = l_run + __shfl_xor(l_run, 32, 64);
+    };
+
+    if (p.has_self) {
+        kv_pass(p.k, p.k_plane, p.vt, p.vt_plane, p.T, p.Tpad, b, o, res_l);
+        const float inv = 1.f / res_l;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= inv;
+    }
+    if (p.has_cross) {
+        float lc;
+        const int kb_batch = p.kv_batch_mod > 0 ? (b % p.kv_batch_mod) : b;
+        kv_pass(p.ky, p.ky_plane, p.vyt, p.vyt_plane, p.L, p.Lpad, kb_batch, oc, lc);
+        const float w = (p.cross_w ? p.cross_w[h] : 1.f) / lc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] += w * oc[i][r];
+    }
+    if (qrow < p.T) {
+        const int64_t base = ((int64_t)b * p.T + qrow) * p.D + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = dt * 32 + 8 * rg + 4 * g;
+                bf16x4 hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hi[i] = f2bf(o[dt][rg * 4 + i]);
+                *reinterpret_cast<bf16x4*>(p.out + base + d0) = hi;
+                if (p.out_np == 2) {
+                    bf16x4 lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lo[i] = f2bf(o[dt][rg * 4 + i] - bf2f(hi[i]));
+                    *reinterpret_cast<bf16x4*>(p.out + p.out_plane + base + d0) = lo;
+                }
+            }
+    }
+}
+
+int launch_attention(const AttnArgs& a, hipStream_t st) {
+    if (a.hd != HD) VB_FAIL(VB_E_INVALID, "attention: head_dim %d unsupported (built for %d)", a.hd, HD);
+    if (a.has_self && (a.Tpad % KT || a.Tpad < a.T)) VB_FAIL(VB_E_INVALID, "attention: Tpad=%d must be a multiple of %d >= T", a.Tpad, KT);
+    if (a.has_cross && (a.Lpad % KT || a.Lpad < a.L)) VB_FAIL(VB_E_INVALID, "attention: Lpad=%d must be a multiple of %d >= L", a.Lpad, KT);
+    if (!a.has_self && !a.has_cross) VB_FAIL(VB_E_INVALID, "attention: nothing to do");
+    AttnDev d;
+    d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
+    d.ky = a.ky.p; d.ky_plane = a.ky.plane; d.vyt = a.vyt.p; d.vyt_plane = a.vyt.plane; d.cross_w = a.cross_w;
+    d.out = a.out.p; d.out_plane = a.out.plane; d.out_np = a.out.np;
+    d.B = a.B; d.T = a.T; d.Tpad = a.Tpad; d.L = a.L; d.Lpad = a.Lpad; d.H = a.H; d.D = a.H * a.hd;
+    d.has_self = a.has_self; d.has_cross = a.has_cross; d.kv_batch_mod = a.kv_batch_mod;
+    d.scale_log2e = a.scale * 1.4426950408889634f;
+    ProfScope prof(1, 4.0 * a.B * a.H * a.T * a.hd * ((a.has_self ? a.T : 0) + (a.has_cross ? a.L : 0)), st);
+    dim3 grid(cdiv(a.T, 128), a.B * a.H);
+    if (a.q.np == 2) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, d);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}

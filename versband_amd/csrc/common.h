@@ -1,0 +1,72 @@
+// Shared device/host helpers for libversband_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A "planes" tensor: bf16 hi plane (+ optional lo plane holding the rounding
+// residual).  value = hi (+ lo).  np == 2 is the parity ("bf16x3") mode: every
+// GEMM runs hi*hi + lo*hi + hi*lo on the bf16 MFMA pipe, which gives ~2^-17
+// relative operand error (fp32-class) at 3/16 of the cost of the f32 MFMA.
+struct Planes {
+    bf16_t* p;
+    int64_t plane;   // element offset between plane 0 and plane 1
+    int np;
+};
+
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }          // RNE
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+
+__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
+    hi = f2bf(v);
+    lo = f2bf(v - bf2f(hi));
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- host side -------------------------------------------------------------
+extern thread_local char g_vb_err[512];
+#ifndef VB_OK
+#define VB_OK 0
+#define VB_E_INVALID (-1)
+#define VB_E_HIP (-2)
+#define VB_E_STATE (-3)
+#endif
+#define VB_FAIL(code, ...)                              \
+    do {                                                \
+        snprintf(g_vb_err, sizeof(g_vb_err), __VA_ARGS__); \
+        return (code);                                  \
+    } while (0)
+#define VB_CHECK_LAUNCH()                                                                   \
+    do {                                                                                    \
+        hipError_t e__ = hipGetLastError();                                                 \
+        if (e__ != hipSuccess) VB_FAIL(VB_E_HIP, "%s:%d launch: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+    } while (0)
+#define VB_HIP(x)                                                                           \
+    do {                                                                                    \
+        hipError_t e__ = (x);                                                               \
+        if (e__ != hipSuccess) VB_FAIL(VB_E_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e__)); \
+    } while (0)
+#define VB_TRY(x)                 \
+    do {                          \
+        int r__ = (x);            \
+        if (r__ != VB_OK) return r__; \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,239 @@
+// fp32 implicit-GEMM Conv1d on the f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32) for the
+// VAE decoder, the HiFi-GAN generator and the DiT stem (gfx950).
+//
+//   out[b][co][t] = beta*out + alpha*( act_out( acc_scale*sum_{ci,j} W[j][ci][co] * act_in(x[b][ci][t + j*dil - pad]) )
+//                                      + bias[co] + res[b][co][t] )
+//
+//  * activations are [B][C][T] (T contiguous); weights are pre-packed [phase][tap][Ci][Co]
+//    (Co contiguous) so both MFMA operands are read from LDS with unit lane stride
+//    (A = W[ci][co..co+31], B = x[ci][t..t+31]) - conflict free without swizzles.
+//  * per 16-channel chunk the input window (tile + (k-1)*dil halo) is staged ONCE and
+//    re-used by all k taps; the pointwise input transform (LeakyReLU, or GroupNorm+swish
+//    from precomputed statistics), zero padding and nearest x2 upsampling are applied
+//    while staging, so no activated/upsampled tensor ever goes to HBM.
+//  * ConvTranspose1d runs as `stride` polyphase sub-convolutions in one launch
+//    (grid.z = batch x phase), each with ceil(k/stride) taps.
+//  * per-batch "weights" (w_bstride) let the VAE's single-head attention (q^T k and P v)
+//    run on the same kernel.
+#include "kernels.h"
+
+#define CK 16
+#define XHALO 64
+
+struct ConvDev {
+    const float* x; int64_t x_bstride; int Ci, T_in, x_bmod;
+    const float* w; int64_t w_bstride; const float* bias;
+    int Co, ntaps, dil, pad, upsample2;
+    int in_act; float in_slope;
+    const float* gn_mean; const float* gn_rstd; const float* gn_gamma; const float* gn_beta; int gn_groups;
+    float* out; int64_t out_bstride; int T_out;
+    const float* res; int64_t res_bstride;
+    float alpha, beta, acc_scale;
+    int out_act; float out_slope;
+    int out_transposed; const float* add; int64_t add_bstride; int add_bmod;
+    int phases, tr_pad;      // phases == 1: ordinary convolution
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) conv1d_f32_kernel(const ConvDev p) {
+    constexpr int CO_TILE = WM * TM * 32;
+    constexpr int T_TILE = WN * TN * 32;
+    constexpr int XW = T_TILE + XHALO;
+    __shared__ float xw[CK * XW];
+    __shared__ float wl[2][CK * CO_TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int z = blockIdx.z;
+    const int b = z / p.phases, ph = z - b * p.phases;
+    const int n0 = blockIdx.x * T_TILE;
+    const int co0 = blockIdx.y * CO_TILE;
+
+    // polyphase geometry (phases == 1 -> in_off = -pad, out index = n)
+    int in_off, out_off, out_stride, n_count;
+    if (p.phases == 1) {
+        in_off = -p.pad; out_off = 0; out_stride = 1; n_count = p.T_out;
+    } else {
+        const int u = p.phases;
+        const int d = p.tr_pad - ph;
+        const int q0 = d > 0 ? (d + u - 1) / u : 0;
+        in_off = q0 - (p.ntaps - 1);
+        out_off = q0 * u + ph - p.tr_pad;
+        out_stride = u;
+        n_count = (p.T_out - out_off + u - 1) / u;
+    }
+    if (n0 >= n_count) return;
+
+    const int halo = (p.ntaps - 1) * p.dil;
+    const int xw_used = T_TILE + halo;
+    const int T_eff = p.upsample2 ? 2 * p.T_in : p.T_in;
+    const int xb = p.x_bmod > 0 ? (b % p.x_bmod) : b;
+    const float* xbase = p.x + (int64_t)xb * p.x_bstride;
+    const float* wbase = p.w + (int64_t)b * p.w_bstride + (int64_t)ph * p.ntaps * p.Ci * p.Co;
+    const int cpg = p.gn_groups > 0 ? (p.Ci / p.gn_groups) : 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int WPT = CK * CO_TILE / 256;   // weight elements per thread per tap tile
+    float wreg[WPT];
+    auto wload = [&](int c0, int j) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            int id = tid + i * 256;
+            int ci = id / CO_TILE, col = id - ci * CO_TILE;
+            int cig = c0 + ci, cog = co0 + col;
+            wreg[i] = (cig < p.Ci && cog < p.Co) ? wbase[((int64_t)j * p.Ci + cig) * p.Co + cog] : 0.f;
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) wl[buf][tid + i * 256] = wreg[i];
+    };
+
+    const int nchunks = (p.Ci + CK - 1) / CK;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK;
+        // ---- stage the activated input window of this channel chunk
+        for (int ci = wave; ci < CK; ci += 4) {
+            const int cig = c0 + ci;
+            const bool cok = cig < p.Ci;
+            float gm = 0.f, gr = 1.f, gg = 1.f, gb = 0.f;
+            if (cok && (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN)) {
+                const int grp = cig / cpg;
+                gm = p.gn_mean[b * p.gn_groups + grp]; gr = p.gn_rstd[b * p.gn_groups + grp];
+                gg = p.gn_gamma[cig]; gb = p.gn_beta[cig];
+            }
+            const float* xrow = xbase + (int64_t)(cok ? cig : 0) * p.T_in;
+            for (int wpos = lane; wpos < xw_used; wpos += 64) {
+                const int idx = n0 + in_off + wpos;
+                float v = 0.f;
+                if (cok && idx >= 0 && idx < T_eff) {
+                    v = xrow[p.upsample2 ? (idx >> 1) : idx];
+                    if (p.in_act == ACT_LRELU) {
+                        v = v > 0.f ? v : v * p.in_slope;
+                    } else if (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN) {
+                        v = (v - gm) * gr * gg + gb;
+                        if (p.in_act == ACT_GN_SWISH) v = v / (1.f + __expf(-v));
+                    }
+                }
+                xw[ci * XW + wpos] = v;
+            }
+        }
+        wload(c0, 0);
+        wstore(0);
+        __syncthreads();
+        for (int j = 0; j < p.ntaps; ++j) {
+            const int buf = j & 1;
+            if (j + 1 < p.ntaps) wload(c0, j + 1);
+            const int xoff = j * p.dil;
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                const int ci = 2 * kk + g;
+                float a[TM], bb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wl[buf][ci * CO_TILE + (wm * TM + i) * 32 + l31];
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) bb[jn] = xw[ci * XW + (wn * TN + jn) * 32 + l31 + xoff];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[jn], acc[i][jn], 0, 0, 0);
+            }
+            if (j + 1 < p.ntaps) wstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane owns output position n, 4 consecutive co per accumulator quad
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + (wn * TN + jn) * 32 + l31;
+        if (n >= n_count) continue;
+        const int t = n * out_stride + out_off;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int cob = co0 + (wm * TM + i) * 32 + 8 * rg + 4 * g;
+                if (cob >= p.Co) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int co = cob + e;
+                    float val = acc[i][jn][rg * 4 + e] * p.acc_scale;
+                    if (co < p.Co) {
+                        if (p.bias) val += p.bias[co];
+                    }
+                    v[e] = val;
+                }
+                if (p.out_transposed) {
+                    // out[b][t][co..co+3]   (Co % 4 == 0 enforced at launch)
+                    float4* dst = reinterpret_cast<float4*>(p.out + (int64_t)b * p.out_bstride + (int64_t)t * p.Co + cob);
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.add) {
+                        const int ab = p.add_bmod > 0 ? (b % p.add_bmod) : b;
+                        const float4 ad = *reinterpret_cast<const float4*>(p.add + (int64_t)ab * p.add_bstride + (int64_t)t * p.Co + cob);
+                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                    }
+                    *dst = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int co = cob + e;
+                        if (co >= p.Co) continue;
+                        float val = v[e];
+                        const int64_t oi = (int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t;
+                        if (p.res) val += p.res[(int64_t)b * p.res_bstride + (int64_t)co * p.T_out + t];
+                        if (p.out_act == ACT_LRELU) val = val > 0.f ? val : val * p.out_slope;
+                        else if (p.out_act == ACT_TANH) val = tanhf(val);
+                        val *= p.alpha;
+                        if (p.beta != 0.f) val += p.beta * p.out[oi];
+                        p.out[oi] = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg(const ConvDev& d, int n_count, int B, hipStream_t st) {
+    dim3 grid(cdiv(n_count, WN * TN * 32), cdiv(d.Co, WM * TM * 32), B * d.phases);
+    hipLaunchKernelGGL((conv1d_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, st, d);
+}
+
+int launch_conv1d(const ConvArgs& a, hipStream_t st) {
+    ConvDev d;
+    d.x = a.x; d.x_bstride = a.x_bstride; d.Ci = a.Ci; d.T_in = a.T_in; d.x_bmod = a.x_bmod;
+    d.w = a.w; d.w_bstride = a.w_bstride; d.bias = a.bias; d.Co = a.Co; d.dil = a.dil; d.pad = a.pad;
+    d.upsample2 = a.upsample2; d.in_act = a.in_act; d.in_slope = a.in_slope;
+    d.gn_mean = a.gn_mean; d.gn_rstd = a.gn_rstd; d.gn_gamma = a.gn_gamma; d.gn_beta = a.gn_beta; d.gn_groups = a.gn_groups;
+    d.out = a.out; d.out_bstride = a.out_bstride; d.T_out = a.T_out; d.res = a.res; d.res_bstride = a.res_bstride;
+    d.alpha = a.alpha; d.beta = a.beta; d.acc_scale = a.acc_scale; d.out_act = a.out_act; d.out_slope = a.out_slope;
+    d.out_transposed = a.out_transposed; d.add = a.add; d.add_bstride = a.add_bstride; d.add_bmod = a.add_bmod;
+    int n_count;
+    if (a.tr_stride > 1) {
+        d.phases = a.tr_stride; d.tr_pad = a.tr_pad; d.ntaps = (a.tr_k + a.tr_stride - 1) / a.tr_stride; d.dil = 1;
+        n_count = cdiv(a.T_out, a.tr_stride);
+        if (a.out_transposed) VB_FAIL(VB_E_INVALID, "conv1d: transposed output not supported with tr_stride");
+    } else {
+        d.phases = 1; d.tr_pad = 0; d.ntaps = a.ksize; n_count = a.T_out;
+    }
+    if ((d.ntaps - 1) * d.dil > XHALO) VB_FAIL(VB_E_INVALID, "conv1d: halo %d exceeds %d", (d.ntaps - 1) * d.dil, XHALO);
+    if (a.out_transposed && (a.Co % 4)) VB_FAIL(VB_E_INVALID, "conv1d: transposed output needs Co%%4==0");
+    if ((a.in_act == ACT_GN_SWISH || a.in_act == ACT_GN) && (a.Ci % a.gn_groups)) VB_FAIL(VB_E_INVALID, "conv1d: Ci %% groups");
+    ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * (a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize), st);
+    if (a.Co > 64) launch_cfg<2, 2, 2, 2>(d, n_count, a.B, st);
+    else if (a.Co > 32) launch_cfg<2, 2, 1, 2>(d, n_count, a.B, st);
+    else launch_cfg<1, 4, 1, 2>(d, n_count, a.B, st);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}

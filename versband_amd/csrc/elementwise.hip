@@ -1,0 +1,635 @@
+// Memory-bound and tiny kernels of the path (gfx950): norms, casts, GEMVs for the
+// per-item conditioning vectors, the Band-MoE router + bucketing, Euler/CFG update,
+// stem helpers, GroupNorm statistics and the VAE attention softmax.
+// All are wave64-shaped: one wave per row with float4 lanes where rows are 768 wide.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------
+// RMSNorm * w, then adaLN modulate, written as bf16 planes (feeds the MFMA GEMMs)
+//   RMSNorm  flag_large_dit_moe.py:52-77 ; modulate :80-81
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rmsnorm_mod_kernel(const float* __restrict__ h, const float* __restrict__ w,
+                                                         const float* shift, const float* scale, int mod_ld, int rows, int D,
+                                                         int T, float eps, Planes out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = h + (int64_t)row * D;
+    float ss = 0.f;
+    for (int k = lane * 4; k < D; k += 256) {
+        float4 v = *reinterpret_cast<const float4*>(x + k);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)D + eps);
+    const int b = row / T;
+    for (int k = lane * 4; k < D; k += 256) {
+        float4 v = *reinterpret_cast<const float4*>(x + k);
+        float4 ww = *reinterpret_cast<const float4*>(w + k);
+        float o[4] = {v.x * r * ww.x, v.y * r * ww.y, v.z * r * ww.z, v.w * r * ww.w};
+        if (scale) {
+            float4 sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * mod_ld + k);
+            float4 sh = *reinterpret_cast<const float4*>(shift + (int64_t)b * mod_ld + k);
+            o[0] = o[0] * (1.f + sc.x) + sh.x; o[1] = o[1] * (1.f + sc.y) + sh.y;
+            o[2] = o[2] * (1.f + sc.z) + sh.z; o[3] = o[3] * (1.f + sc.w) + sh.w;
+        }
+        bf16x4 hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hi[i] = f2bf(o[i]);
+        *reinterpret_cast<bf16x4*>(out.p + (int64_t)row * D + k) = hi;
+        if (out.np == 2) {
+            bf16x4 lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lo[i] = f2bf(o[i] - bf2f(hi[i]));
+            *reinterpret_cast<bf16x4*>(out.p + out.plane + (int64_t)row * D + k) = lo;
+        }
+    }
+}
+int launch_rmsnorm_mod(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D,
+                       int T, float eps, Planes out, hipStream_t st) {
+    if (D % 4) VB_FAIL(VB_E_INVALID, "rmsnorm: D%%4");
+    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, w, shift, scale, mod_ld, rows, D, T > 0 ? T : 1,
+                       eps, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm (optional affine) -> fp32 and/or planes
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* w, const float* bvec, int rows,
+                                                       int D, float eps, float* out32, Planes outp) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += xr[k];
+    const float mean = wave_sum(s) / (float)D;
+    float vs = 0.f;
+    for (int k = lane; k < D; k += 64) { float d = xr[k] - mean; vs += d * d; }
+    const float r = rsqrtf(wave_sum(vs) / (float)D + eps);
+    for (int k = lane; k < D; k += 64) {
+        float o = (xr[k] - mean) * r;
+        if (w) o = o * w[k] + bvec[k];
+        if (out32) out32[(int64_t)row * D + k] = o;
+        if (outp.p) {
+            bf16_t hi = f2bf(o);
+            outp.p[(int64_t)row * D + k] = hi;
+            if (outp.np == 2) outp.p[outp.plane + (int64_t)row * D + k] = f2bf(o - bf2f(hi));
+        }
+    }
+}
+int launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps, float* out32, Planes outp,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, w, b, rows, D, eps, out32, outp);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// casts
+// ---------------------------------------------------------------------------
+__global__ void cast_planes_kernel(const float* __restrict__ x, int64_t n, Planes out) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            float4 v = *reinterpret_cast<const float4*>(x + i);
+            float o[4] = {v.x, v.y, v.z, v.w};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { hi[k] = f2bf(o[k]); lo[k] = f2bf(o[k] - bf2f(hi[k])); }
+            *reinterpret_cast<bf16x4*>(out.p + i) = hi;
+            if (out.np == 2) *reinterpret_cast<bf16x4*>(out.p + out.plane + i) = lo;
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                bf16_t hi = f2bf(x[j]);
+                out.p[j] = hi;
+                if (out.np == 2) out.p[out.plane + j] = f2bf(x[j] - bf2f(hi));
+            }
+        }
+    }
+}
+int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st) {
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_planes_kernel, dim3(blocks), dim3(256), 0, st, x, n, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+__global__ void planes_to_f32_kernel(Planes in, int64_t n, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = bf2f(in.p[i]);
+        if (in.np == 2) v += bf2f(in.p[in.plane + i]);
+        out[i] = v;
+    }
+}
+int launch_planes_to_f32(Planes in, int64_t n, float* out, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3(blocks), dim3(256), 0, st, in, n, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+__global__ void fill_f32_kernel(float* p, int64_t n, float v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+int launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, st, p, n, v);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Row GEMV for the per-item conditioning vectors (t-embedder MLP, adaLN of all blocks in
+// one launch, high-level gates):  out[r][n] = bias[n] + sum_k W[n][k] * act(x[r][k] + x2[r%mod][k])
+// x rows may be gathered (x_row_idx: row r reads x + idx[r]*x_ld) - used for the
+// timestep table lookup.  16 rows x 64 outputs per block; act(x) staged in LDS once.
+// ---------------------------------------------------------------------------
+#define GV_R 16
+#define GV_N 64
+__global__ void __launch_bounds__(256) gemv_rows_kernel(const float* __restrict__ x, int x_ld, const int64_t* x_row_idx,
+                                                       const float* __restrict__ x2, int x2_ld, int x2_mod,
+                                                       const float* __restrict__ W, const float* __restrict__ bias, int R, int N,
+                                                       int K, int act_in, float* out, int out_ld) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [GV_R][K]
+    const int r0 = blockIdx.y * GV_R;
+    const int nr = min(GV_R, R - r0);
+    for (int id = threadIdx.x; id < GV_R * K; id += 256) {
+        int r = id / K, k = id - r * K;
+        float v = 0.f;
+        if (r < nr) {
+            int64_t xr = x_row_idx ? x_row_idx[r0 + r] : (r0 + r);
+            v = x[xr * x_ld + k];
+            if (x2) v += x2[(int64_t)((r0 + r) % x2_mod) * x2_ld + k];
+            if (act_in == 1) v = v / (1.f + expf(-v));
+        }
+        xs[id] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < GV_N / 4; ++i) {
+        const int n = blockIdx.x * GV_N + wave * (GV_N / 4) + i;
+        if (n >= N) break;
+        float acc[GV_R];
+#pragma unroll
+        for (int r = 0; r < GV_R; ++r) acc[r] = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)n * K + k);
+#pragma unroll
+            for (int r = 0; r < GV_R; ++r) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + r * K + k);
+                acc[r] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < GV_R; ++r) {
+            float s = wave_sum(acc[r]);
+            if (lane == 0 && r < nr) out[(int64_t)(r0 + r) * out_ld + n] = s + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* W,
+                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
+    if (K % 4 || K > 2048) VB_FAIL(VB_E_INVALID, "gemv: K=%d must be %%4 and <= 2048", K);
+    dim3 grid(cdiv(N, GV_N), cdiv(R, GV_R));
+    size_t sh = (size_t)GV_R * K * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemv_rows_kernel, grid, dim3(256), sh, st, x, x_ld, idx, x2, x2_ld, x2_mod > 0 ? x2_mod : 1, W, bias, R, N, K,
+                       act_in, out, out_ld);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias, int R,
+                     int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
+    return launch_gemv_rows_idx(x, x_ld, nullptr, x2, x2_ld, x2_mod, W, bias, R, N, K, act_in, out, out_ld, st);
+}
+
+// mean over L rows: [B][L][D] -> [B][D]   (pooled caption, vocal2music_moe.py:410-412)
+__global__ void mean_rows_kernel(const float* __restrict__ x, int B, int L, int D, float* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    int b = i / D, d = i - b * D;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += x[((int64_t)b * L + l) * D + d];
+    out[i] = s / (float)L;
+}
+int launch_mean_rows(const float* x, int B, int L, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(B * D, 256)), dim3(256), 0, st, x, B, L, D, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// stem helpers (vocal2music_moe.py:388-393)
+// ---------------------------------------------------------------------------
+// out[b][d][t] = table[idx[b][t]][d]
+__global__ void embed_t_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table, int B, int T, int D, float* out) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 64 x 4
+    for (int i = ty; i < 64; i += 4) {
+        int t = t0 + i;
+        if (t < T && d0 + tx < D) tile[i][tx] = table[idx[(int64_t)b * T + t] * D + d0 + tx];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int d = d0 + i, t = t0 + tx;
+        if (d < D && t < T) out[((int64_t)b * D + d) * T + t] = tile[tx][i];
+    }
+}
+int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(embed_t_kernel, dim3(cdiv(T, 64), cdiv(D, 64), B), dim3(256), 0, st, idx, table, B, T, D, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+// out[b][c][t] = (a[2t]+a[2t+1])/2 + (b[2t]+b[2t+1])/2    (AvgPool1d(2) of both branches, then sum)
+__global__ void pool_add_kernel(const float* __restrict__ a, const float* __restrict__ bb, int64_t rows, int T_in, float* out) {
+    const int To = T_in / 2;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * To) return;
+    int64_t r = i / To; int t = (int)(i - r * To);
+    const float* pa = a + r * T_in + 2 * t;
+    const float* pb = bb + r * T_in + 2 * t;
+    out[i] = (pa[0] + pa[1]) * 0.5f + (pb[0] + pb[1]) * 0.5f;
+}
+int launch_pool_add(const float* a, const float* b, int B, int C, int T_in, float* out, hipStream_t st) {
+    int64_t n = (int64_t)B * C * (T_in / 2);
+    hipLaunchKernelGGL(pool_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, (int64_t)B * C, T_in, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+// [B][C][T_in] -> [B][T_out][C]; rows t >= T_in repeat the last input row (length fix-up :397-401)
+__global__ void transpose_bct_btc_kernel(const float* __restrict__ in, int C, int T_in, int T_out, float* out) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        int c = c0 + i, t = t0 + tx;
+        int ts = t < T_in ? t : T_in - 1;
+        if (c < C && t < T_out) tile[i][tx] = in[((int64_t)b * C + c) * T_in + ts];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int t = t0 + i, c = c0 + tx;
+        if (t < T_out && c < C) out[((int64_t)b * T_out + t) * C + c] = tile[tx][i];
+    }
+}
+int launch_transpose_bct_btc(const float* in, int B, int C, int T_in, int T_out, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_bct_btc_kernel, dim3(cdiv(T_out, 64), cdiv(C, 64), B), dim3(256), 0, st, in, C, T_in, T_out, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// FinalLayer (vocal2music_moe.py:287-291): LN(no affine, eps) -> modulate -> Linear(D->C) -> out[b][c][t]
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) final_layer_kernel(const float* __restrict__ h, const float* shift, const float* scale,
+                                                         int mod_ld, const float* __restrict__ W, const float* __restrict__ bias,
+                                                         int rows, int D, int T, int C, float eps, float* out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = h + (int64_t)row * D;
+    const int b = row / T, t = row - b * T;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += x[k];
+    const float mean = wave_sum(s) / (float)D;
+    float vs = 0.f;
+    for (int k = lane; k < D; k += 64) { float d = x[k] - mean; vs += d * d; }
+    const float r = rsqrtf(wave_sum(vs) / (float)D + eps);
+    for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        for (int k = lane; k < D; k += 64) {
+            float y = (x[k] - mean) * r;
+            y = y * (1.f + scale[(int64_t)b * mod_ld + k]) + shift[(int64_t)b * mod_ld + k];
+            acc += y * W[(int64_t)c * D + k];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[((int64_t)b * C + c) * T + t] = acc + bias[c];
+    }
+}
+int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                       int rows, int D, int T, int C, float eps, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(final_layer_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, shift, scale, mod_ld, W, bias, rows, D, T, C, eps,
+                       out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CFG + Euler:  x[b] += dt * (v_u + s*(v_c - v_u))     (cfm1_audio.py:160 + fixed-step Euler)
+// v holds the cond rows [0,B) then the uncond rows [B,2B)
+// ---------------------------------------------------------------------------
+__global__ void euler_cfg_kernel(float* x, const float* __restrict__ v, int64_t n, float cfg_scale, const float* dt_table,
+                                 const int* step, float dt_val, int has_uncond) {
+    const float dt = dt_table ? dt_table[step ? *step : 0] : dt_val;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float e = v[i];
+    if (has_uncond) {
+        float eu = v[n + i];
+        e = eu + cfg_scale * (e - eu);
+    }
+    x[i] = x[i] + dt * e;
+}
+int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_scale, const float* dt_table, const int* step,
+                     float dt_val, int has_uncond, hipStream_t st) {
+    int64_t n = (int64_t)B * per;
+    hipLaunchKernelGGL(euler_cfg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, v, n, cfg_scale, dt_table, step,
+                       dt_val, has_uncond);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+// step bookkeeping for graph replay: (reset) step=0 or step+=1; t_idx_cur[:] = t_table[step]
+__global__ void step_advance_kernel(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, int reset) {
+    __shared__ int s;
+    if (threadIdx.x == 0) {
+        s = reset ? 0 : (*step + 1);
+        *step = s;
+    }
+    __syncthreads();
+    int k = s < n_steps ? s : n_steps - 1;
+    for (int i = threadIdx.x; i < Beff; i += blockDim.x) t_idx_cur[i] = t_table[k];
+}
+int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, int reset, hipStream_t st) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, step, t_idx_cur, t_table, n_steps, Beff, reset);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Band-MoE router (vocal2music_moe.py:132-151): one wave per token.
+//   lc = cq . Wg^T + bg ; ic = argmax(lc + G2) ; ia = argmax(la + G3) (first maximum wins, like
+//   torch.max) ; (m_c, m_a) = softmax(hl[b] + G1).   G* are Gumbel draws (-log Exp(1)).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ cq, const float* __restrict__ Wg,
+                                                    const float* __restrict__ bg, const float* __restrict__ la, int la_rows,
+                                                    const float* __restrict__ hl, int hl_ld, const float* __restrict__ g1,
+                                                    const float* __restrict__ g2, const float* __restrict__ g3, int N, int T, int D,
+                                                    int E, int* ic, int* ia, float* mc, float* ma, float* lc_out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* x = cq + (int64_t)n * D;
+    float best = -INFINITY; int bi = 0;
+    for (int e = 0; e < E; ++e) {
+        float acc = 0.f;
+        for (int k = lane * 4; k < D; k += 256) {
+            float4 xv = *reinterpret_cast<const float4*>(x + k);
+            float4 wv = *reinterpret_cast<const float4*>(Wg + (int64_t)e * D + k);
+            acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+        acc = wave_sum(acc) + bg[e];
+        if (lc_out && lane == 0) lc_out[(int64_t)n * E + e] = acc;
+        float z = acc + g2[(int64_t)n * E + e];
+        if (z > best) { best = z; bi = e; }
+    }
+    if (lane == 0) {
+        ic[n] = bi;
+        const float* lar = la + (int64_t)(n % la_rows) * E;
+        float bz = -INFINITY; int ba = 0;
+        for (int e = 0; e < E; ++e) {
+            float z = lar[e] + g3[(int64_t)n * E + e];
+            if (z > bz) { bz = z; ba = e; }
+        }
+        ia[n] = ba;
+        const int b = n / T;
+        float z0 = hl[b * hl_ld + 0] + g1[(int64_t)n * 2 + 0];
+        float z1 = hl[b * hl_ld + 1] + g1[(int64_t)n * 2 + 1];
+        float m = fmaxf(z0, z1);
+        float e0 = expf(z0 - m), e1 = expf(z1 - m);
+        float inv = 1.f / (e0 + e1);
+        mc[n] = e0 * inv;
+        ma[n] = e1 * inv;
+    }
+}
+int launch_router(const float* cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
+                  const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
+                  float* ma, float* lc_out, hipStream_t st) {
+    hipLaunchKernelGGL(router_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E, ic,
+                       ia, mc, ma, lc_out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// idx[n] = first argmax_e (logits[n][e] + gumbel[n][e])   (hard Gumbel-softmax, :81-93)
+__global__ void router_top1_kernel(const float* __restrict__ logits, const float* __restrict__ gum, int N, int E, int* idx) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float best = -INFINITY; int bi = 0;
+    for (int e = 0; e < E; ++e) {
+        float z = logits[(int64_t)n * E + e] + gum[(int64_t)n * E + e];
+        if (z > best) { best = z; bi = e; }
+    }
+    idx[n] = bi;
+}
+int launch_router_top1(const float* logits, const float* gumbel, int N, int E, int* idx, hipStream_t st) {
+    hipLaunchKernelGGL(router_top1_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, logits, gumbel, N, E, idx);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Stable bucketing of tokens by routed expert: slots [0,N) caption groups, [N,2N) acoustic
+// groups; perm[slot] = token, group_off[2E+1].  One 1024-thread block (deterministic order).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bucket_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
+                                                     int* group_off, int* perm) {
+    extern __shared__ int cnt[];            // [2E][1024] counts -> exclusive prefixes ; then [2E] totals
+    int* tot = cnt + 2 * E * 1024;
+    const int tid = threadIdx.x;
+    const int chunk = (N + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(N, lo + chunk);
+    for (int gI = 0; gI < 2 * E; ++gI) cnt[gI * 1024 + tid] = 0;
+    for (int n = lo; n < hi; ++n) {
+        cnt[ic[n] * 1024 + tid] += 1;
+        cnt[(E + ia[n]) * 1024 + tid] += 1;
+    }
+    __syncthreads();
+    // wave w scans group w (and w+16 ...) across the 1024 per-thread counters
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int gI = wave; gI < 2 * E; gI += 16) {
+        int carry = 0;
+        for (int base = 0; base < 1024; base += 64) {
+            int v = cnt[gI * 1024 + base + lane];
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            cnt[gI * 1024 + base + lane] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) tot[gI] = carry;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int gI = 0; gI < 2 * E; ++gI) { group_off[gI] = acc; acc += tot[gI]; }
+        group_off[2 * E] = acc;
+    }
+    __syncthreads();
+    // bases are recomputed from tot[] (group_off lives in global memory, written by thread 0 only)
+    for (int n = lo; n < hi; ++n) {
+        int gc = ic[n], ga = E + ia[n];
+        int oc = 0, oa = 0;
+        for (int gI = 0; gI < gc; ++gI) oc += tot[gI];
+        for (int gI = 0; gI < ga; ++gI) oa += tot[gI];
+        int pc = cnt[gc * 1024 + tid]++;
+        int pa = cnt[ga * 1024 + tid]++;
+        perm[oc + pc] = n;
+        perm[oa + pa] = n;
+    }
+}
+int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st) {
+    if (E > 16) VB_FAIL(VB_E_INVALID, "bucket: E=%d > 16", E);
+    size_t sh = (size_t)(2 * E * 1024 + 2 * E) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bucket_kernel, dim3(1), dim3(1024), sh, st, ic, ia, N, E, group_off, perm);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Gumbel noise generator for the production path: G = -log(-log(1-u)), u from splitmix64
+// keyed by (seed, stream, element) - independent of launch geometry and world size.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// element (row n = (branch*B + b)*T + t, e) of stream (seed, clip_base + b, nfe, branch, block, gate)
+__global__ void fill_gumbel_kernel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base,
+                                   int nfe_base, const int* step, int block, int gate) {
+    const int64_t n_el = (int64_t)n_branch * B * T * width;
+    const int nfe = nfe_base + (step ? *step : 0);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n_el; i += stride) {
+        int64_t row = i / width; int e = (int)(i - row * width);
+        int bb = (int)(row / T), t = (int)(row - (int64_t)bb * T);
+        int branch = bb / B, b = bb - branch * B;
+        uint64_t key = splitmix64(seed ^ splitmix64((uint64_t)(clip_base + b) * 0x9E3779B97F4A7C15ull + 0x1234567ull));
+        key = splitmix64(key + (((uint64_t)nfe * 2 + branch) << 20) + ((uint64_t)block << 8) + (uint64_t)gate);
+        uint64_t z = splitmix64(key + ((uint64_t)t * width + e + 1) * 0x9E3779B97F4A7C15ull);
+        float u = (float)((z >> 40) + 1) * (1.0f / 16777218.0f);      // (0,1)
+        float ex = -log1pf(-u);
+        ex = fmaxf(ex, 1e-30f);
+        out[i] = -logf(ex);
+    }
+}
+int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
+                       const int* step, int block, int gate, hipStream_t st) {
+    int64_t n = (int64_t)n_branch * B * T * width;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_gumbel_kernel, dim3(blocks), dim3(256), 0, st, out, B, n_branch, T, width, seed, clip_base, nfe_base, step,
+                       block, gate);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// out[n][e] = x[n] . W[e] + b[e]   (acoustic gate logits, precompute)
+__global__ void __launch_bounds__(256) rows_dot_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, int N, int D, int E, float* out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    for (int e = 0; e < E; ++e) {
+        float acc = 0.f;
+        for (int k = lane * 4; k < D; k += 256) {
+            float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * D + k);
+            float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)e * D + k);
+            acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[(int64_t)n * E + e] = acc + bias[e];
+    }
+}
+int launch_rows_dot(const float* x, const float* W, const float* bias, int N, int D, int E, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(rows_dot_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, x, W, bias, N, D, E, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics (autoencoder1d.py:165-166): one block per (b, group); the group's
+// channels are contiguous in [B][C][T].  Two-pass mean / biased variance.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int C, int T, int groups, float eps, float* mean,
+                                                      float* rstd) {
+    __shared__ float red[4];
+    __shared__ float s_mean;
+    const int bg = blockIdx.x;
+    const int64_t n = (int64_t)(C / groups) * T;
+    const float* p = x + (int64_t)bg * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) s_mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    __syncthreads();
+    const float m = s_mean;
+    float v = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) { float d = p[i] - m; v += d * d; }
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mean[bg] = m;
+        rstd[bg] = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+    }
+}
+int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, float* mean, float* rstd, hipStream_t st) {
+    if (C % groups) VB_FAIL(VB_E_INVALID, "gn_stats: C%%groups");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, st, x, C, T, groups, eps, mean, rstd);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// softmax over the last dim of s[B][R][Cc], written transposed: out_t[b][c][r]
+__global__ void __launch_bounds__(256) softmax_rows_t_kernel(const float* __restrict__ s, int R, int Cc, float* out_t) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* p = s + ((int64_t)b * R + row) * Cc;
+    float m = -INFINITY;
+    for (int c = lane; c < Cc; c += 64) m = fmaxf(m, p[c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < Cc; c += 64) sum += expf(p[c] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int c = lane; c < Cc; c += 64) out_t[((int64_t)b * Cc + c) * R + row] = expf(p[c] - m) * inv;
+}
+int launch_softmax_rows_t(const float* s, int B, int R, int Ccols, float* out_t, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_rows_t_kernel, dim3(cdiv(R, 4), B), dim3(256), 0, st, s, R, Ccols, out_t);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}

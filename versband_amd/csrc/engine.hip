@@ -1,0 +1,646 @@
+// Host-side runtime of libversband_hip.so: context, DiT engine (conditioning precompute,
+// one network evaluation, the CFG/Euler sampling loop), the conv-net executor used by the
+// VAE decoder and the HiFi-GAN generator, and the extern "C" entry points of
+// include/versband_hip.h.  No device allocation happens here: all scratch is carved out of
+// caller buffers (sizes from *_bytes()).
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/versband_hip.h"
+#include "kernels.h"
+
+thread_local char g_vb_err[512] = "";
+
+// ---- kernel-class profiling -----------------------------------------------------------------
+#define PROF_CLASSES 3
+#define PROF_POOL 32768
+static int g_prof_mask = 0;
+static std::vector<hipEvent_t> g_prof_ev;          // pool of events (pairs)
+static size_t g_prof_next = 0;
+struct ProfRec { int cls; size_t ev; };
+static std::vector<ProfRec> g_prof_recs;
+static double g_prof_flops[PROF_CLASSES] = {0, 0, 0};
+static long long g_prof_launches[PROF_CLASSES] = {0, 0, 0};
+static thread_local size_t g_prof_open = (size_t)-1;
+void prof_start(int cls, double flops, hipStream_t st) {
+    g_prof_open = (size_t)-1;
+    if (!(g_prof_mask & (1 << cls))) return;
+    g_prof_flops[cls] += flops;
+    g_prof_launches[cls] += 1;
+    if (g_prof_next + 2 > g_prof_ev.size()) return;      // pool exhausted: launch counted, not timed
+    g_prof_open = g_prof_next;
+    g_prof_next += 2;
+    (void)hipEventRecord(g_prof_ev[g_prof_open], st);
+}
+void prof_stop(int cls, hipStream_t st) {
+    if (g_prof_open == (size_t)-1) return;
+    (void)hipEventRecord(g_prof_ev[g_prof_open + 1], st);
+    g_prof_recs.push_back(ProfRec{cls, g_prof_open});
+    g_prof_open = (size_t)-1;
+}
+
+struct NetProgram {
+    std::vector<vb_net_op> ops;
+    std::vector<vb_buf_desc> bufs;
+    int in_ch = 0, out_ch = 0, out_tmul = 1;
+    bool loaded = false;
+};
+struct vb_ctx {
+    int device = 0;
+    bool dit_loaded = false;
+    vb_dit_config cfg;
+    vb_dit_weights w;
+    NetProgram nets[2];
+};
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    template <typename T> T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off = align_up(off + n * sizeof(T));
+        return p;
+    }
+};
+static inline int pad64(int x) { return (x + 63) / 64 * 64; }
+static inline Planes mkp(bf16_t* p, int64_t numel, int np) { return Planes{p, numel, np}; }
+static inline Planes wpl(const void* p, int64_t numel, int np) { return Planes{(bf16_t*)p, numel, np}; }
+
+// ------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------
+struct CondL {
+    float* ac; float* cemb;
+    bf16_t* ky[VB_MAX_DEPTH]; bf16_t* vyt[VB_MAX_DEPTH]; bf16_t* kc[VB_MAX_DEPTH]; bf16_t* vct[VB_MAX_DEPTH];
+    float* la[VB_MAX_DEPTH];
+    int64_t n_k, n_vt; int Lpad;
+    size_t total;
+};
+static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T, int L) {
+    CondL o;
+    Carver cv(base);
+    const int Beff = B * nb, D = c.hidden, hd = D / c.heads;
+    o.Lpad = pad64(L);
+    o.n_k = (int64_t)Beff * L * D;
+    o.n_vt = (int64_t)Beff * c.heads * hd * o.Lpad;
+    o.ac = cv.take<float>((size_t)B * T * D);
+    o.cemb = cv.take<float>((size_t)Beff * D);
+    for (int i = 0; i < c.depth; ++i) {
+        o.ky[i] = cv.take<bf16_t>(o.n_k * c.np);
+        o.vyt[i] = cv.take<bf16_t>(o.n_vt * c.np);
+        o.kc[i] = cv.take<bf16_t>(o.n_k * c.np);
+        o.vct[i] = cv.take<bf16_t>(o.n_vt * c.np);
+        o.la[i] = cv.take<float>((size_t)B * T * c.num_experts);
+    }
+    o.total = cv.off;
+    return o;
+}
+
+struct WsL {
+    int* step; int64_t* t_idx_cur; int64_t* t_table; float* dt_table;
+    float *temb0, *temb, *mod_all, *hl, *h, *cq32, *mc, *ma, *y32, *g1, *g2, *g3, *v;
+    bf16_t *u, *q, *k, *vt, *a, *qm, *cqa, *Hs, *y, *Hf;
+    int *ic, *ia, *group_off, *perm;
+    // precompute temporaries
+    float *tA, *tB, *tC, *tD, *tE, *cap_pre, *cap32, *pooled, *pooled_ln;
+    bf16_t *t5p, *gel, *capp, *yp;
+    int64_t n_tok, n_vt; int Tpad, MODW;
+    size_t total;
+};
+static WsL carve_ws(void* base, const vb_dit_config& c, int B, int nb, int T, int L) {
+    WsL o;
+    Carver cv(base);
+    const int Beff = B * nb, D = c.hidden, H = c.ffn_hidden, E = c.num_experts, hd = D / c.heads;
+    const int64_t N = (int64_t)Beff * T;
+    o.n_tok = N; o.Tpad = pad64(T); o.MODW = c.depth * 6 * D + 2 * D;
+    o.n_vt = (int64_t)Beff * c.heads * hd * o.Tpad;
+    o.step = cv.take<int>(16);
+    o.t_idx_cur = cv.take<int64_t>(Beff);
+    o.t_table = cv.take<int64_t>(1024);
+    o.dt_table = cv.take<float>(1024);
+    o.temb0 = cv.take<float>((size_t)Beff * D);
+    o.temb = cv.take<float>((size_t)Beff * D);
+    o.mod_all = cv.take<float>((size_t)Beff * o.MODW);
+    o.hl = cv.take<float>((size_t)Beff * c.depth * 2);
+    o.h = cv.take<float>(N * D);
+    o.cq32 = cv.take<float>(N * D);
+    o.mc = cv.take<float>(N);
+    o.ma = cv.take<float>(N);
+    o.y32 = cv.take<float>(N * D);
+    o.g1 = cv.take<float>(N * 2);
+    o.g2 = cv.take<float>(N * E);
+    o.g3 = cv.take<float>(N * E);
+    o.v = cv.take<float>((size_t)Beff * c.in_channels * T);
+    o.u = cv.take<bf16_t>(N * D * c.np);
+    o.q = cv.take<bf16_t>(N * D * c.np);
+    o.k = cv.take<bf16_t>(N * D * c.np);
+    o.vt = cv.take<bf16_t>(o.n_vt * c.np);
+    o.a = cv.take<bf16_t>(N * D * c.np);
+    o.qm = cv.take<bf16_t>(N * D * c.np);
+    o.cqa = cv.take<bf16_t>(N * D * c.np);
+    o.Hs = cv.take<bf16_t>(2 * N * H * c.np);
+    o.y = cv.take<bf16_t>(N * D * c.np);
+    o.Hf = cv.take<bf16_t>(N * E * H * c.np);
+    o.ic = cv.take<int>(N);
+    o.ia = cv.take<int>(N);
+    o.group_off = cv.take<int>(2 * E + 1);
+    o.perm = cv.take<int>(2 * N);
+    // precompute temporaries
+    const int T_mel = 2 * T + 8;
+    o.tA = cv.take<float>((size_t)B * D * T_mel);
+    o.tB = cv.take<float>((size_t)B * D * T_mel);
+    o.tC = cv.take<float>((size_t)B * D * T_mel);
+    o.tD = cv.take<float>((size_t)B * D * T_mel);
+    o.tE = cv.take<float>((size_t)B * D * T_mel);
+    const int64_t NL = (int64_t)Beff * L;
+    o.t5p = cv.take<bf16_t>(NL * c.ori_dim * 2);
+    o.gel = cv.take<bf16_t>(NL * D * 2);
+    o.cap_pre = cv.take<float>(NL * D);
+    o.cap32 = cv.take<float>(NL * D);
+    o.capp = cv.take<bf16_t>(NL * D * 2);
+    o.yp = cv.take<bf16_t>(NL * D * 2);
+    o.pooled = cv.take<float>((size_t)Beff * D);
+    o.pooled_ln = cv.take<float>((size_t)Beff * D);
+    o.total = cv.off;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// DiT: conditioning precompute
+// ------------------------------------------------------------------------------------------
+static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, const int64_t* beats, int B, int nb, int T, int T_mel,
+                          int L, void* cond, void* ws, hipStream_t st) {
+    const vb_dit_config& c = ctx->cfg;
+    const vb_dit_weights& w = ctx->w;
+    if (T_mel > 2 * T + 8) VB_FAIL(VB_E_INVALID, "precompute: T_mel=%d too long for T=%d", T_mel, T);
+    const int T_ac = T_mel / 2;
+    if (abs(T - T_ac) > 2) VB_FAIL(VB_E_INVALID, "precompute: latent length %d vs conditioning length %d differ by more than 2 "
+                                   "(vocal2music_moe.py:397 would leave the shapes mismatched)", T, T_ac);
+    CondL cd = carve_cond(cond, c, B, nb, T, L);
+    WsL s = carve_ws(ws, c, B, nb, T, L);
+    const int Beff = B * nb, D = c.hidden, E = c.num_experts, hd = D / c.heads, np = c.np;
+    const int64_t NL = (int64_t)Beff * L;
+
+    // ---- acoustic stem (vocal2music_moe.py:388-393)
+    ConvArgs cv;
+    for (int which = 0; which < 2; ++which) {
+        VB_TRY(launch_embed_t(which ? beats : midi, which ? w.beats_emb : w.midi_emb, B, T_mel, D, s.tA, st));
+        cv = ConvArgs();
+        cv.x = s.tA; cv.x_bstride = (int64_t)D * T_mel; cv.Ci = D; cv.T_in = T_mel;
+        cv.w = which ? w.beats_conv_w : w.midi_conv_w; cv.bias = which ? w.beats_conv_b : w.midi_conv_b;
+        cv.Co = D; cv.ksize = 5; cv.pad = 2; cv.out = which ? s.tC : s.tB; cv.out_bstride = (int64_t)D * T_mel; cv.T_out = T_mel;
+        cv.out_act = ACT_LRELU; cv.out_slope = 0.01f; cv.B = B;
+        VB_TRY(launch_conv1d(cv, st));
+    }
+    VB_TRY(launch_pool_add(s.tB, s.tC, B, D, T_mel, s.tD, st));
+    cv = ConvArgs();
+    cv.x = s.tD; cv.x_bstride = (int64_t)D * T_ac; cv.Ci = D; cv.T_in = T_ac; cv.w = w.final_proj_w; cv.bias = w.final_proj_b;
+    cv.Co = D; cv.ksize = 1; cv.pad = 0; cv.out = s.tE; cv.out_bstride = (int64_t)D * T_ac; cv.T_out = T_ac; cv.B = B;
+    VB_TRY(launch_conv1d(cv, st));
+    VB_TRY(launch_transpose_bct_btc(s.tE, B, D, T_ac, T, cd.ac, st));
+
+    // ---- caption embedding (ConditionEmbedder, flag_large_dit_moe.py:149-160) in split precision
+    Planes t5p = mkp(s.t5p, NL * c.ori_dim, 2);
+    VB_TRY(launch_cast_planes(t5, NL * c.ori_dim, t5p, st));
+    GemmArgs g;
+    g.A = t5p.p; g.a_plane = t5p.plane; g.lda = c.ori_dim; g.B = (const bf16_t*)w.c_emb0; g.b_plane = (int64_t)D * c.ori_dim;
+    g.ldb = c.ori_dim; g.M = (int)NL; g.N = D; g.K = c.ori_dim; g.nseg = 3; g.epi = EPI_GELU_PLANES; g.bias = w.c_emb0_b;
+    g.out = mkp(s.gel, NL * D, 2); g.ldc = D;
+    VB_TRY(launch_gemm(g, st));
+    g = GemmArgs();
+    g.A = s.gel; g.a_plane = NL * D; g.lda = D; g.B = (const bf16_t*)w.c_emb2; g.b_plane = (int64_t)D * D; g.ldb = D;
+    g.M = (int)NL; g.N = D; g.K = D; g.nseg = 3; g.epi = EPI_F32; g.bias = w.c_emb2_b; g.out32 = s.cap_pre; g.ldc32 = D;
+    VB_TRY(launch_gemm(g, st));
+    Planes capp = mkp(s.capp, NL * D, 2);
+    VB_TRY(launch_layernorm(s.cap_pre, w.c_ln_w, w.c_ln_b, (int)NL, D, 1e-5f, s.cap32, capp, st));
+    // pooled caption -> cap_embedder (vocal2music_moe.py:367-370,410-413)
+    VB_TRY(launch_mean_rows(s.cap32, Beff, L, D, s.pooled, st));
+    VB_TRY(launch_layernorm(s.pooled, w.cap_ln_w, w.cap_ln_b, Beff, D, 1e-5f, s.pooled_ln, Planes{nullptr, 0, 1}, st));
+    VB_TRY(launch_gemv_rows(s.pooled_ln, D, nullptr, 0, 1, w.cap_lin_w, w.cap_lin_b, Beff, D, D, 0, cd.cemb, D, st));
+
+    // ---- per block: context K/V for Attention and MoE.cross_attention, acoustic gate logits
+    for (int i = 0; i < c.depth; ++i) {
+        const vb_dit_block_weights& bw = w.blocks[i];
+        Planes yp = mkp(s.yp, NL * D, 2);
+        VB_TRY(launch_rmsnorm_mod(s.cap32, bw.y_norm_w, nullptr, nullptr, 0, (int)NL, D, L, c.norm_eps, yp, st));
+        VB_HIP(hipMemsetAsync(cd.vyt[i], 0, (size_t)cd.n_vt * np * sizeof(bf16_t), st));
+        VB_HIP(hipMemsetAsync(cd.vct[i], 0, (size_t)cd.n_vt * np * sizeof(bf16_t), st));
+        for (int which = 0; which < 4; ++which) {
+            // 0: ky = y Wk_y^T   1: vy^T   2: kc = cap Wk^T + bk   3: vc^T
+            g = GemmArgs();
+            const bool from_y = which < 2;
+            g.A = from_y ? yp.p : capp.p; g.a_plane = NL * D; g.lda = D;
+            const void* W = which == 0 ? bw.wky : which == 1 ? bw.wvy : which == 2 ? bw.wk_m : bw.wv_m;
+            g.B = (const bf16_t*)W; g.b_plane = (int64_t)D * D; g.ldb = D; g.M = (int)NL; g.N = D; g.K = D; g.nseg = 3;
+            g.bias = which == 2 ? bw.bk_m : which == 3 ? bw.bv_m : nullptr;
+            if (which == 0 || which == 2) {
+                g.epi = EPI_PLANES; g.out = mkp(which == 0 ? cd.ky[i] : cd.kc[i], cd.n_k, np); g.ldc = D;
+            } else {
+                g.epi = EPI_HEADS_T; g.out = mkp(which == 1 ? cd.vyt[i] : cd.vct[i], cd.n_vt, np);
+                g.T = L; g.H = c.heads; g.hd = hd; g.Tpad = cd.Lpad;
+            }
+            VB_TRY(launch_gemm(g, st));
+        }
+        VB_TRY(launch_rows_dot(cd.ac, bw.wag, bw.bag, B * T, D, E, cd.la[i], st));
+    }
+    return VB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// DiT: one evaluation (both CFG branches batched: rows [0,B) cond, [B,2B) uncond)
+// ------------------------------------------------------------------------------------------
+static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int noise_step,
+                       const int* step_ptr, int B, int nb, int T, int L, float* v_out, int32_t* route_out, void* ws, bool zero_vt,
+                       hipStream_t st) {
+    const vb_dit_config& c = ctx->cfg;
+    const vb_dit_weights& w = ctx->w;
+    CondL cd = carve_cond(const_cast<void*>(cond), c, B, nb, T, L);
+    WsL s = carve_ws(ws, c, B, nb, T, L);
+    const int Beff = B * nb, D = c.hidden, H = c.ffn_hidden, E = c.num_experts, hd = D / c.heads, np = c.np;
+    const int N = (int)s.n_tok, MODW = s.MODW, band = D / E;
+    const int nseg = np == 2 ? 3 : 1;
+    const int64_t ND = (int64_t)N * D;
+    if (T > c.max_len) VB_FAIL(VB_E_INVALID, "dit_forward: T=%d exceeds the RoPE table (max_len=%d, vocal2music_moe.py:421)", T, c.max_len);
+    if (zero_vt) VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * np * sizeof(bf16_t), st));
+
+    // ---- timestep embedding + all adaLN modulations + high-level gate logits (depend on (t, caption) only)
+    VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, t_idx, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, Beff, D, 256, 0, s.temb0, D, st));
+    VB_TRY(launch_gemv_rows(s.temb0, D, nullptr, 0, 1, w.t_mlp2_w, w.t_mlp2_b, Beff, D, D, 1, s.temb, D, st));
+    VB_TRY(launch_gemv_rows(s.temb, D, cd.cemb, D, Beff, w.adaln_w, w.adaln_b, Beff, MODW, D, 1, s.mod_all, MODW, st));
+    VB_TRY(launch_gemv_rows(s.temb, D, nullptr, 0, 1, w.hl_w, w.hl_b, Beff, c.depth * 2, D, 0, s.hl, c.depth * 2, st));
+
+    // ---- h = proj_in(x)^T + acoustic   (vocal2music_moe.py:395,415)
+    {
+        ConvArgs cv;
+        cv.x = x; cv.x_bstride = (int64_t)c.in_channels * T; cv.Ci = c.in_channels; cv.T_in = T; cv.x_bmod = B;
+        cv.w = w.proj_in_w; cv.bias = w.proj_in_b; cv.Co = D; cv.ksize = 5; cv.pad = 2;
+        cv.out = s.h; cv.out_bstride = (int64_t)T * D; cv.T_out = T; cv.out_transposed = 1;
+        cv.add = cd.ac; cv.add_bstride = (int64_t)T * D; cv.add_bmod = B; cv.B = Beff;
+        VB_TRY(launch_conv1d(cv, st));
+    }
+
+    Planes u = mkp(s.u, ND, np), q = mkp(s.q, ND, np), k = mkp(s.k, ND, np), vt = mkp(s.vt, s.n_vt, np), a = mkp(s.a, ND, np);
+    Planes qm = mkp(s.qm, ND, np), cqa = mkp(s.cqa, ND, np), Hs = mkp(s.Hs, (int64_t)2 * N * H, np), y = mkp(s.y, ND, np);
+    Planes Hf = mkp(s.Hf, (int64_t)N * E * H, np);
+    const float scale = 1.0f / sqrtf((float)hd);
+
+    for (int i = 0; i < c.depth; ++i) {
+        const vb_dit_block_weights& bw = w.blocks[i];
+        const float* mod = s.mod_all + (size_t)i * 6 * D;    // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        // ---- attention (flag_large_dit_moe.py:323-406)
+        VB_TRY(launch_rmsnorm_mod(s.h, bw.attn_norm_w, mod, mod + D, MODW, N, D, T, c.norm_eps, u, st));
+        GemmArgs g;
+        g.A = u.p; g.a_plane = ND; g.lda = D; g.B = (const bf16_t*)bw.wqkv; g.b_plane = (int64_t)3 * D * D; g.ldb = D;
+        g.M = N; g.N = 3 * D; g.K = D; g.nseg = nseg; g.epi = EPI_QKV_ROPE; g.q = q; g.k = k; g.vt = vt;
+        g.rope_cos = w.rope_cos; g.rope_sin = w.rope_sin; g.H = c.heads; g.hd = hd; g.Tpad = s.Tpad; g.D = D; g.T = T;
+        VB_TRY(launch_gemm(g, st));
+        AttnArgs at;
+        at.q = q; at.k = k; at.vt = vt; at.ky = mkp(cd.ky[i], cd.n_k, np); at.vyt = mkp(cd.vyt[i], cd.n_vt, np);
+        at.cross_w = bw.cross_w; at.out = a; at.B = Beff; at.T = T; at.Tpad = s.Tpad; at.L = L; at.Lpad = cd.Lpad; at.H = c.heads;
+        at.hd = hd; at.has_self = 1; at.has_cross = 1; at.kv_batch_mod = 0; at.scale = scale;
+        VB_TRY(launch_attention(at, st));
+        g = GemmArgs();
+        g.A = a.p; g.a_plane = ND; g.lda = D; g.B = (const bf16_t*)bw.wo; g.b_plane = (int64_t)D * D; g.ldb = D;
+        g.M = N; g.N = D; g.K = D; g.nseg = nseg; g.epi = EPI_RESID_GATE; g.out32 = s.h; g.ldc32 = D; g.gate = mod + 2 * D;
+        g.gate_ld = MODW; g.T = T;
+        VB_TRY(launch_gemm(g, st));
+
+        // ---- Band-MoE (vocal2music_moe.py:117-185)
+        VB_TRY(launch_rmsnorm_mod(s.h, bw.ffn_norm_w, mod + 3 * D, mod + 4 * D, MODW, N, D, T, c.norm_eps, u, st));
+        g = GemmArgs();
+        g.A = u.p; g.a_plane = ND; g.lda = D; g.B = (const bf16_t*)bw.wq_m; g.b_plane = (int64_t)D * D; g.ldb = D;
+        g.M = N; g.N = D; g.K = D; g.nseg = nseg; g.epi = EPI_PLANES; g.bias = bw.bq_m; g.out = qm; g.ldc = D;
+        VB_TRY(launch_gemm(g, st));
+        at = AttnArgs();
+        at.q = qm; at.k = Planes{nullptr, 0, np}; at.vt = Planes{nullptr, 0, np}; at.ky = mkp(cd.kc[i], cd.n_k, np);
+        at.vyt = mkp(cd.vct[i], cd.n_vt, np); at.cross_w = nullptr; at.out = cqa; at.B = Beff; at.T = T; at.Tpad = s.Tpad; at.L = L;
+        at.Lpad = cd.Lpad; at.H = c.heads; at.hd = hd; at.has_self = 0; at.has_cross = 1; at.kv_batch_mod = 0; at.scale = scale;
+        VB_TRY(launch_attention(at, st));
+        g = GemmArgs();
+        g.A = cqa.p; g.a_plane = ND; g.lda = D; g.B = (const bf16_t*)bw.wo_m; g.b_plane = (int64_t)D * D; g.ldb = D;
+        g.M = N; g.N = D; g.K = D; g.nseg = nseg; g.epi = EPI_F32; g.bias = bw.bo_m; g.out32 = s.cq32; g.ldc32 = D;
+        VB_TRY(launch_gemm(g, st));
+        // gates
+        const float *g1, *g2, *g3;
+        if (noise && noise->g1) {
+            const size_t so = (size_t)noise_step * c.depth + i;
+            g1 = noise->g1 + so * N * 2; g2 = noise->g2 + so * N * E; g3 = noise->g3 + so * N * E;
+        } else {
+            const uint64_t seed = noise ? noise->seed : 0;
+            const int64_t clip = noise ? noise->clip_base : 0;
+            const int nfe0 = noise ? noise->nfe : 0;
+            VB_TRY(launch_fill_gumbel(s.g1, B, nb, T, 2, seed, clip, nfe0, step_ptr, i, 0, st));
+            VB_TRY(launch_fill_gumbel(s.g2, B, nb, T, E, seed, clip, nfe0, step_ptr, i, 1, st));
+            VB_TRY(launch_fill_gumbel(s.g3, B, nb, T, E, seed, clip, nfe0, step_ptr, i, 2, st));
+            g1 = s.g1; g2 = s.g2; g3 = s.g3;
+        }
+        VB_TRY(launch_router(s.cq32, bw.wcg, bw.bcg, cd.la[i], B * T, s.hl + i * 2, c.depth * 2, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
+                             s.ma, nullptr, st));
+        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st));
+        if (route_out) {
+            VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
+            VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 1) * N, s.ia, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
+        }
+        // routed experts: hidden = silu(u W1^T) * (u W3^T) for both groups in one grouped launch
+        g = GemmArgs();
+        g.A = u.p; g.a_plane = ND; g.lda = D; g.a_rows = s.perm; g.B = (const bf16_t*)bw.w13; g.b_plane = (int64_t)2 * E * 2 * H * D;
+        g.ldb = D; g.b_group_stride = (int64_t)2 * H * D; g.M = 2 * N; g.N = 2 * H; g.K = D; g.nseg = nseg; g.ngroups = 2 * E;
+        g.group_off = s.group_off; g.epi = EPI_SWIGLU; g.out = Hs; g.ldc = H;
+        VB_TRY(launch_gemm(g, st));
+        // y = m_c * FFN^c(u)  (store), then y += m_a * FFN^a(u) (planes out)
+        g = GemmArgs();
+        g.A = Hs.p; g.a_plane = Hs.plane; g.lda = H; g.B = (const bf16_t*)bw.w2; g.b_plane = (int64_t)2 * E * D * H; g.ldb = H;
+        g.b_group_stride = (int64_t)D * H; g.M = N; g.N = D; g.K = H; g.nseg = nseg; g.ngroups = E; g.group_off = s.group_off;
+        g.epi = EPI_SCATTER_F32; g.out32 = s.y32; g.ldc32 = D; g.rows_out = s.perm; g.row_scale = s.mc;
+        VB_TRY(launch_gemm(g, st));
+        g.B = (const bf16_t*)bw.w2 + (int64_t)E * D * H; g.group_off = s.group_off + E; g.epi = EPI_SCATTER_ADD_PLANES;
+        g.y32_in = s.y32; g.row_scale = s.ma; g.out = y; g.ldc = D;
+        VB_TRY(launch_gemm(g, st));
+        // band experts (frequency-MoE): expert e sees only channel band e and produces only band e
+        g = GemmArgs();
+        g.A = y.p; g.a_plane = ND; g.lda = D; g.a_koff_group = band; g.B = (const bf16_t*)bw.w13f; g.b_plane = (int64_t)E * 2 * H * band;
+        g.ldb = band; g.b_group_stride = (int64_t)2 * H * band; g.M = N; g.N = 2 * H; g.K = band; g.nseg = nseg; g.ngroups = E;
+        g.epi = EPI_SWIGLU; g.out = Hf; g.ldc = E * H; g.c_noff_group = H;
+        VB_TRY(launch_gemm(g, st));
+        g = GemmArgs();
+        g.A = Hf.p; g.a_plane = Hf.plane; g.lda = E * H; g.a_koff_group = H; g.B = (const bf16_t*)bw.w2f; g.b_plane = (int64_t)E * band * H;
+        g.ldb = H; g.b_group_stride = (int64_t)band * H; g.M = N; g.N = band; g.K = H; g.nseg = nseg; g.ngroups = E;
+        g.epi = EPI_RESID_GATE; g.out32 = s.h; g.ldc32 = D; g.c_noff_group = band; g.gate = mod + 5 * D; g.gate_ld = MODW; g.T = T;
+        VB_TRY(launch_gemm(g, st));
+    }
+    // ---- FinalLayer (vocal2music_moe.py:287-291) -> v [Beff][C][T]
+    const float* modf = s.mod_all + (size_t)c.depth * 6 * D;
+    VB_TRY(launch_final_layer(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, v_out, st));
+    return VB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// conv-net executor (VAE decoder, HiFi-GAN)
+// ------------------------------------------------------------------------------------------
+static size_t net_ws_bytes(const NetProgram& n, int B, int T, std::vector<size_t>* offs) {
+    size_t off = 0;
+    if (offs) offs->clear();
+    for (const vb_buf_desc& d : n.bufs) {
+        size_t tl = (size_t)T * d.tmul;
+        size_t el = d.square ? tl * tl : (size_t)d.channels * tl;
+        if (offs) offs->push_back(off);
+        off = align_up(off + el * B * sizeof(float));
+    }
+    return off;
+}
+static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float* out, void* ws, hipStream_t st) {
+    NetProgram& n = ctx->nets[which];
+    if (!n.loaded) VB_FAIL(VB_E_STATE, "net %d not loaded", which);
+    std::vector<size_t> offs;
+    net_ws_bytes(n, B, T, &offs);
+    auto ptr = [&](int id) -> float* {
+        if (id == VB_BUF_INPUT) return const_cast<float*>(in);
+        if (id == VB_BUF_OUTPUT) return out;
+        if (id < 0) return nullptr;
+        return reinterpret_cast<float*>(static_cast<char*>(ws) + offs[id]);
+    };
+    auto tlen = [&](int id) -> int {
+        if (id == VB_BUF_INPUT) return T;
+        if (id == VB_BUF_OUTPUT) return T * n.out_tmul;
+        return T * n.bufs[id].tmul;
+    };
+    auto chans = [&](int id) -> int {
+        if (id == VB_BUF_INPUT) return n.in_ch;
+        if (id == VB_BUF_OUTPUT) return n.out_ch;
+        return n.bufs[id].channels;
+    };
+    auto bstride = [&](int id) -> int64_t {
+        if (id >= 0 && n.bufs[id].square) return (int64_t)tlen(id) * tlen(id);
+        return (int64_t)chans(id) * tlen(id);
+    };
+    for (size_t oi = 0; oi < n.ops.size(); ++oi) {
+        const vb_net_op& o = n.ops[oi];
+        if (o.kind == VB_OP_GN_STATS) {
+            float* stp = ptr(o.stats);
+            VB_TRY(launch_gn_stats(ptr(o.x), B, o.Ci, tlen(o.x), o.gn_groups, 1e-6f, stp, stp + (size_t)B * o.gn_groups, st));
+        } else if (o.kind == VB_OP_SOFTMAX_T) {
+            VB_TRY(launch_softmax_rows_t(ptr(o.x), B, tlen(o.x), tlen(o.x), ptr(o.out), st));
+        } else if (o.kind == VB_OP_CONV) {
+            ConvArgs a;
+            a.x = ptr(o.x); a.x_bstride = bstride(o.x); a.T_in = tlen(o.x);
+            a.Ci = o.Ci > 0 ? o.Ci : tlen(o.x);            // dynamic channel counts: the VAE attention contracts over T
+            if (o.w_buf != -1) { a.w = ptr(o.w_buf); a.w_bstride = bstride(o.w_buf); } else { a.w = o.w; }
+            a.bias = o.bias; a.Co = o.Co > 0 ? o.Co : tlen(o.out); a.ksize = o.ksize; a.dil = o.dil; a.pad = o.pad; a.upsample2 = o.upsample2;
+            a.in_act = o.in_act; a.in_slope = o.in_slope;
+            if (o.stats >= 0) {
+                float* stp = ptr(o.stats);
+                a.gn_mean = stp; a.gn_rstd = stp + (size_t)B * o.gn_groups; a.gn_gamma = o.gn_gamma; a.gn_beta = o.gn_beta;
+                a.gn_groups = o.gn_groups;
+            }
+            a.out = ptr(o.out); a.out_bstride = bstride(o.out); a.T_out = tlen(o.out);
+            if (o.res != -1) { a.res = ptr(o.res); a.res_bstride = bstride(o.res); }
+            a.alpha = o.alpha; a.beta = o.beta; a.acc_scale = o.acc_scale; a.out_act = o.out_act; a.out_slope = o.out_slope;
+            a.out_transposed = o.out_transposed; a.B = B; a.tr_stride = o.tr_stride; a.tr_pad = o.tr_pad; a.tr_k = o.tr_k;
+            VB_TRY(launch_conv1d(a, st));
+        } else {
+            VB_FAIL(VB_E_INVALID, "net op %zu: bad kind %d", oi, o.kind);
+        }
+    }
+    return VB_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// extern "C"
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* vb_last_error(void) { return g_vb_err; }
+int vb_abi_version(void) { return 1; }
+
+int vb_prof_enable(int class_mask) {
+    if (class_mask && g_prof_ev.empty()) {
+        g_prof_ev.resize(2 * PROF_POOL);
+        for (auto& e : g_prof_ev) VB_HIP(hipEventCreate(&e));
+    }
+    g_prof_mask = class_mask;
+    g_prof_next = 0;
+    g_prof_recs.clear();
+    for (int i = 0; i < PROF_CLASSES; ++i) { g_prof_flops[i] = 0; g_prof_launches[i] = 0; }
+    return VB_OK;
+}
+int vb_prof_read(int cls, double* ms_sum, double* flops, int64_t* launches, int64_t* timed) {
+    if (cls < 0 || cls >= PROF_CLASSES) VB_FAIL(VB_E_INVALID, "prof_read: class %d", cls);
+    VB_HIP(hipDeviceSynchronize());
+    double ms = 0; int64_t n = 0;
+    for (const ProfRec& r : g_prof_recs) {
+        if (r.cls != cls) continue;
+        float t = 0.f;
+        VB_HIP(hipEventElapsedTime(&t, g_prof_ev[r.ev], g_prof_ev[r.ev + 1]));
+        ms += t; ++n;
+    }
+    *ms_sum = ms; *flops = g_prof_flops[cls]; *launches = g_prof_launches[cls]; *timed = n;
+    return VB_OK;
+}
+
+int vb_ctx_create(int device, vb_ctx** out) {
+    if (!out) VB_FAIL(VB_E_INVALID, "ctx_create: null out");
+    int n = 0;
+    VB_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) VB_FAIL(VB_E_INVALID, "ctx_create: device %d of %d", device, n);
+    VB_HIP(hipSetDevice(device));
+    vb_ctx* c = new vb_ctx();
+    c->device = device;
+    memset(&c->cfg, 0, sizeof(c->cfg));
+    memset(&c->w, 0, sizeof(c->w));
+    *out = c;
+    return VB_OK;
+}
+int vb_ctx_destroy(vb_ctx* ctx) {
+    delete ctx;
+    return VB_OK;
+}
+
+int vb_dit_load(vb_ctx* ctx, const vb_dit_config* cfg, const vb_dit_weights* w) {
+    if (!ctx || !cfg || !w) VB_FAIL(VB_E_INVALID, "dit_load: null argument");
+    if (cfg->depth < 1 || cfg->depth > VB_MAX_DEPTH) VB_FAIL(VB_E_INVALID, "dit_load: depth %d", cfg->depth);
+    if (cfg->np != 1 && cfg->np != 2) VB_FAIL(VB_E_INVALID, "dit_load: np %d", cfg->np);
+    if (cfg->hidden % cfg->heads || cfg->hidden / cfg->heads != 96)
+        VB_FAIL(VB_E_INVALID, "dit_load: head_dim %d unsupported (kernels are built for 96)", cfg->hidden / (cfg->heads ? cfg->heads : 1));
+    if (cfg->hidden % cfg->num_experts || (cfg->hidden / cfg->num_experts) % 8) VB_FAIL(VB_E_INVALID, "dit_load: band width must be a multiple of 8");
+    if (cfg->context_dim != cfg->hidden) VB_FAIL(VB_E_INVALID, "dit_load: context_dim must equal hidden_size (vocal2music_moe.py:367-373)");
+    if (cfg->num_experts > 16) VB_FAIL(VB_E_INVALID, "dit_load: num_experts %d > 16", cfg->num_experts);
+    ctx->cfg = *cfg;
+    ctx->w = *w;
+    ctx->dit_loaded = true;
+    return VB_OK;
+}
+size_t vb_dit_cond_bytes(const vb_dit_config* cfg, int B, int n_branch, int T, int L) {
+    return carve_cond(nullptr, *cfg, B, n_branch, T, L).total;
+}
+size_t vb_dit_workspace_bytes(const vb_dit_config* cfg, int B, int n_branch, int T, int L) {
+    return carve_ws(nullptr, *cfg, B, n_branch, T, L).total;
+}
+int vb_dit_precompute_cond(vb_ctx* ctx, const float* t5, const int64_t* midi, const int64_t* beats, int B, int n_branch, int T,
+                           int T_mel, int L, void* cond, void* ws, void* stream) {
+    if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "precompute_cond: DiT not loaded");
+    if (n_branch < 1 || n_branch > 2 || B < 1) VB_FAIL(VB_E_INVALID, "precompute_cond: B=%d n_branch=%d", B, n_branch);
+    return dit_precompute(ctx, t5, midi, beats, B, n_branch, T, T_mel, L, cond, ws, (hipStream_t)stream);
+}
+int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int B, int n_branch,
+                   int T, int L, float* v_out, int32_t* route_out, void* ws, void* stream) {
+    if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "dit_forward: DiT not loaded");
+    return dit_forward(ctx, x, t_idx, cond, noise, 0, nullptr, B, n_branch, T, L, v_out, route_out, ws, true, (hipStream_t)stream);
+}
+int vb_euler_cfg_step(float* x, const float* v, int B, int64_t per_item, float cfg_scale, float dt, int has_uncond, void* stream) {
+    return launch_euler_cfg(x, v, B, per_item, cfg_scale, nullptr, nullptr, dt, has_uncond, (hipStream_t)stream);
+}
+int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps,
+                  const int64_t* t_idx_table, const float* dt_table, float cfg_scale, const vb_noise* noise, float* traj, void* ws,
+                  void* stream) {
+    if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "sample_cfg: DiT not loaded");
+    if (n_steps < 1 || n_steps > 1024) VB_FAIL(VB_E_INVALID, "sample_cfg: n_steps=%d", n_steps);
+    hipStream_t st = (hipStream_t)stream;
+    const vb_dit_config& c = ctx->cfg;
+    WsL s = carve_ws(ws, c, B, n_branch, T, L);
+    const int Beff = B * n_branch;
+    const int64_t per = (int64_t)c.in_channels * T;
+    VB_HIP(hipMemcpyAsync(s.t_table, t_idx_table, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    VB_HIP(hipMemcpyAsync(s.dt_table, dt_table, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, st));
+    VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * c.np * sizeof(bf16_t), st));
+    if (traj) VB_HIP(hipMemcpyAsync(traj, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    for (int k = 0; k < n_steps; ++k) {
+        VB_TRY(launch_step_ctl(s.step, s.t_idx_cur, s.t_table, n_steps, Beff, k == 0, st));
+        VB_TRY(dit_forward(ctx, x, s.t_idx_cur, cond, noise, k, s.step, B, n_branch, T, L, s.v, nullptr, ws, false, st));
+        VB_TRY(launch_euler_cfg(x, s.v, B, per, cfg_scale, s.dt_table, s.step, 0.f, n_branch == 2, st));
+        if (traj) VB_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * B * per, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    return VB_OK;
+}
+
+int vb_net_load(vb_ctx* ctx, int which, const vb_net_op* ops, int n_ops, const vb_buf_desc* bufs, int n_bufs, int in_channels,
+                int out_channels, int out_tmul) {
+    if (!ctx || which < 0 || which > 1 || !ops || n_ops < 1) VB_FAIL(VB_E_INVALID, "net_load: bad argument");
+    NetProgram& n = ctx->nets[which];
+    n.ops.assign(ops, ops + n_ops);
+    n.bufs.assign(bufs, bufs + n_bufs);
+    for (int i = 0; i < n_ops; ++i) {
+        const vb_net_op& o = ops[i];
+        const int ids[5] = {o.x, o.out, o.res, o.stats, o.w_buf};
+        for (int id : ids)
+            if (id >= n_bufs || (id < -3)) VB_FAIL(VB_E_INVALID, "net_load: op %d references buffer %d of %d", i, id, n_bufs);
+    }
+    n.in_ch = in_channels; n.out_ch = out_channels; n.out_tmul = out_tmul; n.loaded = true;
+    return VB_OK;
+}
+size_t vb_net_workspace_bytes(vb_ctx* ctx, int which, int B, int T) {
+    if (!ctx || which < 0 || which > 1 || !ctx->nets[which].loaded) return 0;
+    return net_ws_bytes(ctx->nets[which], B, T, nullptr);
+}
+int vb_vae_decode(vb_ctx* ctx, const float* z, int B, int T, float* mel, void* ws, void* stream) {
+    if (!ctx) VB_FAIL(VB_E_INVALID, "vae_decode: null ctx");
+    return net_run(ctx, VB_NET_VAE, z, B, T, mel, ws, (hipStream_t)stream);
+}
+int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream) {
+    if (!ctx) VB_FAIL(VB_E_INVALID, "hifigan_forward: null ctx");
+    return net_run(ctx, VB_NET_VOCODER, mel, B, T, wav, ws, (hipStream_t)stream);
+}
+
+// ---- unit kernels --------------------------------------------------------------------------
+int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D, int T,
+                        float eps, void* out_planes, int np, void* stream) {
+    return launch_rmsnorm_mod(h, w, shift, scale, mod_ld, rows, D, T, eps, mkp((bf16_t*)out_planes, (int64_t)rows * D, np),
+                              (hipStream_t)stream);
+}
+int vb_router_top1(const float* logits, const float* gumbel, int N, int E, int32_t* idx, void* stream) {
+    return launch_router_top1(logits, gumbel, N, E, idx, (hipStream_t)stream);
+}
+int vb_route_bucket(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, void* stream) {
+    return launch_bucket(ic, ia, N, E, group_off, perm, (hipStream_t)stream);
+}
+int vb_gemm_bf16(const void* A, const void* Bw, const float* bias, int M, int N, int K, int np, float* C, void* stream) {
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.a_plane = (int64_t)M * K; g.lda = K; g.B = (const bf16_t*)Bw; g.b_plane = (int64_t)N * K; g.ldb = K;
+    g.M = M; g.N = N; g.K = K; g.nseg = np == 2 ? 3 : 1; g.epi = EPI_F32; g.bias = bias; g.out32 = C; g.ldc32 = N;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+int vb_grouped_swiglu(const void* u, const int32_t* perm, const int32_t* group_off, int G, int n_slots, const void* w13,
+                      const void* w2, const float* row_scale, int D, int H, int np, void* hidden, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int nseg = np == 2 ? 3 : 1;
+    GemmArgs g;
+    g.A = (const bf16_t*)u; g.a_plane = (int64_t)n_slots * D; g.lda = D; g.a_rows = perm; g.B = (const bf16_t*)w13;
+    g.b_plane = (int64_t)G * 2 * H * D; g.ldb = D; g.b_group_stride = (int64_t)2 * H * D; g.M = n_slots; g.N = 2 * H; g.K = D;
+    g.nseg = nseg; g.ngroups = G; g.group_off = group_off; g.epi = EPI_SWIGLU; g.out = mkp((bf16_t*)hidden, (int64_t)n_slots * H, np);
+    g.ldc = H;
+    VB_TRY(launch_gemm(g, st));
+    g = GemmArgs();
+    g.A = (const bf16_t*)hidden; g.a_plane = (int64_t)n_slots * H; g.lda = H; g.B = (const bf16_t*)w2; g.b_plane = (int64_t)G * D * H;
+    g.ldb = H; g.b_group_stride = (int64_t)D * H; g.M = n_slots; g.N = D; g.K = H; g.nseg = nseg; g.ngroups = G;
+    g.group_off = group_off; g.epi = EPI_SCATTER_F32; g.out32 = out; g.ldc32 = D; g.rows_out = perm; g.row_scale = row_scale;
+    return launch_gemm(g, st);
+}
+int vb_attention(const void* q, const void* k, const void* vt, const void* ky, const void* vyt, const float* cross_w, int B, int T,
+                 int Tpad, int L, int Lpad, int H, int hd, int np, void* out, void* stream) {
+    AttnArgs a;
+    const int64_t ND = (int64_t)B * T * H * hd;
+    a.q = wpl(q, ND, np); a.k = wpl(k, ND, np); a.vt = wpl(vt, (int64_t)B * H * hd * Tpad, np);
+    a.ky = wpl(ky, (int64_t)B * L * H * hd, np); a.vyt = wpl(vyt, (int64_t)B * H * hd * Lpad, np);
+    a.cross_w = cross_w; a.out = wpl(out, ND, np); a.B = B; a.T = T; a.Tpad = Tpad; a.L = L; a.Lpad = Lpad; a.H = H; a.hd = hd;
+    a.has_self = k != nullptr; a.has_cross = ky != nullptr; a.kv_batch_mod = 0; a.scale = 1.0f / sqrtf((float)hd);
+    return launch_attention(a, (hipStream_t)stream);
+}
+int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil, int pad,
+                  int tr_stride, int tr_pad, int tr_k, int T_out, int in_act, float in_slope, const float* res, float* out,
+                  void* stream) {
+    ConvArgs a;
+    a.x = x; a.x_bstride = (int64_t)Ci * T_in; a.Ci = Ci; a.T_in = T_in; a.w = w; a.bias = bias; a.Co = Co; a.ksize = ksize;
+    a.dil = dil; a.pad = pad; a.in_act = in_act; a.in_slope = in_slope; a.out = out; a.out_bstride = (int64_t)Co * T_out;
+    a.T_out = T_out; a.res = res; a.res_bstride = (int64_t)Co * T_out; a.B = B; a.tr_stride = tr_stride; a.tr_pad = tr_pad; a.tr_k = tr_k;
+    return launch_conv1d(a, (hipStream_t)stream);
+}
+int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
+                   void* stream) {
+    return launch_fill_gumbel(out, B, n_branch, T, width, seed, clip_base, nfe, nullptr, block, gate, (hipStream_t)stream);
+}
+int vb_cast_planes(const float* x, int64_t n, void* out, int np, void* stream) {
+    return launch_cast_planes(x, n, mkp((bf16_t*)out, n, np), (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+// bf16 MFMA GEMM for the DiT (gfx950):  C[m][n] = sum_k A[m][k] * B[n][k]
+//
+//  * 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 as 2x2
+//    v_mfma_f32_32x32x16_bf16 tiles, fp32 accumulation.
+//  * Both operands are K-contiguous; tiles are register-staged into an XOR-swizzled
+//    LDS image (16-B chunk c of row r lives at chunk c ^ ((r>>1)&7)) so the
+//    ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct 16-B slots.
+//  * LDS is double buffered: global loads of tile t+1 are in flight while the MFMAs
+//    of tile t run; one barrier per K tile.
+//  * The MFMA is issued "swapped" (weights as the A operand) so a lane owns one
+//    output ROW m and 4 consecutive output COLUMNS per accumulator quad: pairwise
+//    epilogues (RoPE, SwiGLU) are lane-local and stores are 8-16 B per lane.
+//  * nseg == 3 is the split-precision mode: the K loop walks (A_hi,B_hi), (A_lo,B_hi),
+//    (A_hi,B_lo) - three bf16 passes give fp32-class products.
+//  * Grouped problems (Band-MoE experts): the grid's y index walks the m-tiles of all
+//    groups; group row ranges come from a device array written by the bucket kernel.
+#include "kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define NTHREADS 256
+
+struct GemmDev {
+    const bf16_t* A; int64_t a_plane; int lda; const int* a_rows; int a_koff_group;
+    const bf16_t* B; int64_t b_plane; int ldb; int64_t b_group_stride;
+    int M, N, K, nseg, ngroups; const int* group_off; int c_noff_group;
+    const float* bias; int64_t bias_group_stride;
+    bf16_t* out; int64_t out_plane; int out_np; int ldc;
+    float* out32; int ldc32;
+    const float* gate; int gate_ld; int T;
+    const int* rows_out; const float* row_scale; const float* y32_in;
+    bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
+    const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
+};
+
+__device__ __forceinline__ void store4p(bf16_t* base, int64_t plane, int np, int64_t idx, const float v[4]) {
+    bf16x4 hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hi[i] = f2bf(v[i]);
+    *reinterpret_cast<bf16x4*>(base + idx) = hi;
+    if (np == 2) {
+        bf16x4 lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lo[i] = f2bf(v[i] - bf2f(hi[i]));
+        *reinterpret_cast<bf16x4*>(base + plane + idx) = lo;
+    }
+}
+__device__ __forceinline__ void store1p(bf16_t* base, int64_t plane, int np, int64_t idx, float v) {
+    bf16_t hi = f2bf(v);
+    base[idx] = hi;
+    if (np == 2) base[plane + idx] = f2bf(v - bf2f(hi));
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue4(const GemmDev& p, int g, int m, int n, float v[4]) {
+    // m: global row (slot) index, n: column within the group's [0,N), 4 consecutive columns, all < N
+    if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T) {
+        if (p.bias) {
+            const float* b = p.bias + g * p.bias_group_stride + n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += b[i];
+        }
+    }
+    if constexpr (EPI == EPI_PLANES) {
+        store4p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + n, v);
+    } else if constexpr (EPI == EPI_GELU_PLANES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f));
+        store4p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + n, v);
+    } else if constexpr (EPI == EPI_F32) {
+        *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_RESID_GATE) {
+        int col = g * p.c_noff_group + n;
+        float4* dst = reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + col);
+        const float4 gt = *reinterpret_cast<const float4*>(p.gate + (int64_t)(m / p.T) * p.gate_ld + col);
+        float4 h = *dst;
+        h.x += gt.x * v[0]; h.y += gt.y * v[1]; h.z += gt.z * v[2]; h.w += gt.w * v[3];
+        *dst = h;
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        float o0 = silu_f(v[0]) * v[1], o1 = silu_f(v[2]) * v[3];
+        int64_t idx = (int64_t)m * p.ldc + g * p.c_noff_group + (n >> 1);
+        bf16_t h0 = f2bf(o0), h1 = f2bf(o1);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 hv; hv[0] = h0; hv[1] = h1;
+        *reinterpret_cast<bf16x2*>(p.out + idx) = hv;
+        if (p.out_np == 2) {
+            bf16x2 lv; lv[0] = f2bf(o0 - bf2f(h0)); lv[1] = f2bf(o1 - bf2f(h1));
+            *reinterpret_cast<bf16x2*>(p.out + p.out_plane + idx) = lv;
+        }
+    } else if constexpr (EPI == EPI_SCATTER_F32) {
+        int tok = p.rows_out[m];
+        float s = p.row_scale[tok];
+        *reinterpret_cast<float4*>(p.out32 + (int64_t)tok * p.ldc32 + n) = make_float4(s * v[0], s * v[1], s * v[2], s * v[3]);
+    } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
+        int tok = p.rows_out[m];
+        float s = p.row_scale[tok];
+        const float4 y = *reinterpret_cast<const float4*>(p.y32_in + (int64_t)tok * p.ldc32 + n);
+        float o[4] = {y.x + s * v[0], y.y + s * v[1], y.z + s * v[2], y.w + s * v[3]};
+        store4p(p.out, p.out_plane, p.out_np, (int64_t)tok * p.ldc + n, o);
+    } else if constexpr (EPI == EPI_HEADS_T) {
+        int b = m / p.T, t = m - b * p.T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int nn = n + i;
+            int h = nn / p.hd, d = nn - h * p.hd;
+            store1p(p.out, p.out_plane, p.out_np, ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t, v[i]);
+        }
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+        int sec = n / p.D;               // uniform over the 4 columns (D % 4 == 0)
+        int nn = n - sec * p.D;
+        int b = m / p.T, t = m - b * p.T;
+        if (sec < 2) {
+            int jd = (nn % p.hd) >> 1;   // rotary pair index inside the head
+            const float* cs = p.rope_cos + (int64_t)t * (p.hd / 2) + jd;
+            const float* sn = p.rope_sin + (int64_t)t * (p.hd / 2) + jd;
+            float c0 = cs[0], c1 = cs[1], s0 = sn[0], s1 = sn[1];
+            float o[4] = {v[0] * c0 - v[1] * s0, v[0] * s0 + v[1] * c0, v[2] * c1 - v[3] * s1, v[2] * s1 + v[3] * c1};
+            if (sec == 0) store4p(p.q, p.q_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
+            else store4p(p.k, p.k_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int c = nn + i;
+                int h = c / p.hd, d = c - h * p.hd;
+                store1p(p.vt, p.vt_plane, p.qkv_np, ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t, v[i]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int lds_off(int row, int c) {   // byte offset inside a [128][64] bf16 tile
+    return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(NTHREADS) gemm_bf16_kernel(const GemmDev p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * BK * 2];   // [buf][A/B][16 KB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- which (group, m-tile) is this block -------------------------------------
+    int g = 0, row0, rows_end;
+    {
+        int tmg = blockIdx.y;
+        if (p.group_off) {
+            bool found = false;
+            for (int gi = 0; gi < p.ngroups; ++gi) {
+                int lo = p.group_off[gi], hi = p.group_off[gi + 1];
+                int nt = (hi - lo + BM - 1) / BM;
+                if (tmg < nt) { g = gi; row0 = lo + tmg * BM; rows_end = hi; found = true; break; }
+                tmg -= nt;
+            }
+            if (!found) return;
+        } else {
+            g = blockIdx.z;              // groups that share the row range (band experts)
+            row0 = tmg * BM; rows_end = p.M;
+            if (row0 >= rows_end) return;
+        }
+    }
+    const int n0 = blockIdx.x * BN;
+    const int K = p.K;
+    const int KT = (K + BK - 1) / BK;
+    const int total = KT * p.nseg;
+
+    // ---- per-thread global load slots: 4 chunks of A, 4 chunks of B ----------------
+    const bf16_t* aptr[4]; const bf16_t* bptr[4]; bool aval[4], bval[4]; int lds_w[4];
+    const int cch = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = (tid >> 3) + i * 32;
+        int slot = row0 + r;
+        aval[i] = slot < rows_end;
+        int arow = aval[i] ? (p.a_rows ? p.a_rows[slot] : slot) : 0;
+        aptr[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + cch * 8;
+        int nrow = n0 + r;
+        bval[i] = nrow < p.N;
+        bptr[i] = p.B + g * p.b_group_stride + (int64_t)(bval[i] ? nrow : 0) * p.ldb + cch * 8;
+        lds_w[i] = lds_off(r, cch);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int t) {
+        int seg = t / KT;
+        int k0 = (t - seg * KT) * BK;
+        int64_t ao = (seg == 1) ? p.a_plane : 0;
+        int64_t bo = (seg == 2) ? p.b_plane : 0;
+        bool kin = (k0 + cch * 8) < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (aval[i] && kin) ? *reinterpret_cast<const uint4*>(aptr[i] + ao + k0) : make_uint4(0, 0, 0, 0);
+            rb[i] = (bval[i] && kin) ? *reinterpret_cast<const uint4*>(bptr[i] + bo + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(&lds[buf][0][lds_w[i]]) = ra[i];
+            *reinterpret_cast<uint4*>(&lds[buf][1][lds_w[i]]) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < total; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < total) gload(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bf[2];
+            int c = ks * 2 + fk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(&lds[buf][0][lds_off(wr * 64 + i * 32 + frow, c)]);
+                bf[i] = *reinterpret_cast<const bf16x8*>(&lds[buf][1][lds_off(wc * 64 + i * 32 + frow, c)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < total) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns row m = ..+(lane&31); 4 consecutive n per accumulator quad
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int slot = row0 + wr * 64 + i * 32 + frow;
+        if (slot >= rows_end) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
+                if (n >= p.N) continue;     // N % 4 == 0 is required
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                epilogue4<EPI>(p, g, slot, n, v);
+            }
+        }
+    }
+}
+
+template <int EPI>
+static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0) return VB_OK;
+    if (a.N % 4 || a.K % 8 || a.lda % 8 || a.ldb % 8) VB_FAIL(VB_E_INVALID, "gemm: N%%4, K%%8, lda%%8, ldb%%8 must be 0 (N=%d K=%d)", a.N, a.K);
+    if (a.nseg != 1 && a.nseg != 3) VB_FAIL(VB_E_INVALID, "gemm: nseg must be 1 or 3");
+    GemmDev d;
+    d.A = a.A; d.a_plane = a.a_plane; d.lda = a.lda; d.a_rows = a.a_rows; d.a_koff_group = a.a_koff_group;
+    d.B = a.B; d.b_plane = a.b_plane; d.ldb = a.ldb; d.b_group_stride = a.b_group_stride;
+    d.M = a.M; d.N = a.N; d.K = a.K; d.nseg = a.nseg; d.ngroups = a.ngroups; d.group_off = a.group_off;
+    d.c_noff_group = a.c_noff_group; d.bias = a.bias; d.bias_group_stride = a.bias_group_stride;
+    d.out = a.out.p; d.out_plane = a.out.plane; d.out_np = a.out.np; d.ldc = a.ldc;
+    d.out32 = a.out32; d.ldc32 = a.ldc32; d.gate = a.gate; d.gate_ld = a.gate_ld; d.T = a.T > 0 ? a.T : 1;
+    d.rows_out = a.rows_out; d.row_scale = a.row_scale; d.y32_in = a.y32_in;
+    d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
+    d.qkv_np = a.q.np; d.rope_cos = a.rope_cos; d.rope_sin = a.rope_sin; d.H = a.H; d.hd = a.hd > 0 ? a.hd : 1;
+    d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
+    ProfScope prof(0, 2.0 * a.M * a.N * a.K * ((a.group_off || a.ngroups <= 1) ? 1 : a.ngroups), st);
+    int mt = a.group_off ? (cdiv(a.M, BM) + a.ngroups) : cdiv(a.M, BM);
+    dim3 grid(cdiv(a.N, BN), mt, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
+    switch (a.epi) {
+        case EPI_PLANES: launch_t<EPI_PLANES>(d, grid, st); break;
+        case EPI_F32: launch_t<EPI_F32>(d, grid, st); break;
+        case EPI_QKV_ROPE: launch_t<EPI_QKV_ROPE>(d, grid, st); break;
+        case EPI_RESID_GATE: launch_t<EPI_RESID_GATE>(d, grid, st); break;
+        case EPI_SWIGLU: launch_t<EPI_SWIGLU>(d, grid, st); break;
+        case EPI_SCATTER_F32: launch_t<EPI_SCATTER_F32>(d, grid, st); break;
+        case EPI_SCATTER_ADD_PLANES: launch_t<EPI_SCATTER_ADD_PLANES>(d, grid, st); break;
+        case EPI_GELU_PLANES: launch_t<EPI_GELU_PLANES>(d, grid, st); break;
+        case EPI_HEADS_T: launch_t<EPI_HEADS_T>(d, grid, st); break;
+        default: VB_FAIL(VB_E_INVALID, "gemm: bad epilogue %d", a.epi);
+    }
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}

@@ -1,0 +1,131 @@
+// Internal launch API shared by the engines and the C-ABI wrappers.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// bf16 MFMA GEMM   C[m][n] = sum_k A[m][k] * B[n][k]   (both operands K-contiguous)
+// ---------------------------------------------------------------------------
+enum GemmEpi {
+    EPI_PLANES = 0,          // out planes[m][coff+n] = v (+bias)
+    EPI_F32 = 1,             // out32[m][coff+n] = v (+bias)
+    EPI_QKV_ROPE = 2,        // q,k planes with RoPE; v written transposed per head
+    EPI_RESID_GATE = 3,      // out32[m][coff+n] += gate[b(m)][coff+n] * v
+    EPI_SWIGLU = 4,          // interleaved (w1,w3) columns -> planes[m][coff + n/2] = silu(v0)*v1
+    EPI_SCATTER_F32 = 5,     // out32[rows_out[m]][n] = row_scale[rows_out[m]] * v
+    EPI_SCATTER_ADD_PLANES = 6,  // planes[tok][n] = y32_in[tok][n] + row_scale[tok]*v
+    EPI_GELU_PLANES = 7,     // planes = gelu_erf(v + bias)
+    EPI_HEADS_T = 8,         // planes[((b*H+h)*hd+d)*Tpad + t] = v (+bias),  m = b*T+t, n = h*hd+d
+    EPI_COUNT = 9
+};
+
+struct GemmArgs {
+    const bf16_t* A = nullptr; int64_t a_plane = 0; int lda = 0;
+    const int* a_rows = nullptr;      // optional row gather (slot -> token)
+    int a_koff_group = 0;             // A column offset per group index
+    const bf16_t* B = nullptr; int64_t b_plane = 0; int ldb = 0; int64_t b_group_stride = 0;
+    int M = 0, N = 0, K = 0;
+    int nseg = 1;                     // 1 = plain bf16, 3 = bf16x3 split precision
+    int ngroups = 1; const int* group_off = nullptr;   // device [ngroups+1] slot offsets (null: one group [0,M))
+    int c_noff_group = 0;             // output column offset per group
+    int epi = EPI_F32;
+    const float* bias = nullptr; int64_t bias_group_stride = 0;
+    Planes out = {nullptr, 0, 1}; int ldc = 0;
+    float* out32 = nullptr; int ldc32 = 0;
+    const float* gate = nullptr; int gate_ld = 0; int T = 1;
+    const int* rows_out = nullptr; const float* row_scale = nullptr; const float* y32_in = nullptr;
+    Planes q = {nullptr, 0, 1}, k = {nullptr, 0, 1}, vt = {nullptr, 0, 1};
+    const float* rope_cos = nullptr; const float* rope_sin = nullptr;
+    int H = 1, hd = 1, Tpad = 0, D = 0;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// flash attention over bf16 planes (head_dim 96): out = softmax(q k^T s) v  [+ w_h * softmax(q ky^T s) vy]
+// ---------------------------------------------------------------------------
+struct AttnArgs {
+    Planes q;            // [B*T][H*hd]
+    Planes k;            // [B*T][H*hd]       (self; may be null when !has_self)
+    Planes vt;           // [B][H][hd][Tpad]
+    Planes ky;           // [B*L][H*hd]       (cross; may be null)
+    Planes vyt;          // [B][H][hd][Lpad]
+    const float* cross_w;  // [H] per-head weight of the cross term (null -> 1)
+    Planes out;          // [B*T][H*hd]
+    int B, T, Tpad, L, Lpad, H, hd;
+    int has_self, has_cross;
+    int kv_batch_mod;    // cross K/V batch index = b % kv_batch_mod (0: = b)
+    float scale;
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// fp32 MFMA implicit-GEMM Conv1d   out[b][co][t] over x[b][ci][t]
+// ---------------------------------------------------------------------------
+enum ConvAct { ACT_NONE = 0, ACT_LRELU = 1, ACT_GN_SWISH = 2, ACT_TANH = 3, ACT_GN = 4 };
+struct ConvArgs {
+    const float* x = nullptr; int64_t x_bstride = 0; int Ci = 0; int T_in = 0; int x_bmod = 0;
+    const float* w = nullptr;        // packed [phase][tap][Ci][Co]
+    int64_t w_bstride = 0;           // per-batch weights (VAE attention), 0 = shared
+    const float* bias = nullptr;
+    int Co = 0, ksize = 1, dil = 1, pad = 0;
+    int upsample2 = 0;               // nearest x2 on the input (T_in is the un-upsampled length)
+    int in_act = ACT_NONE; float in_slope = 0.f;
+    const float* gn_mean = nullptr; const float* gn_rstd = nullptr;   // [B][groups]
+    const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int gn_groups = 32;
+    float* out = nullptr; int64_t out_bstride = 0; int T_out = 0;
+    const float* res = nullptr; int64_t res_bstride = 0;   // residual [b][co][t] (same layout as out)
+    float alpha = 1.f;               // out = beta*out + alpha*(acc*acc_scale + bias + res)
+    float beta = 0.f;
+    float acc_scale = 1.f;
+    int out_act = ACT_NONE; float out_slope = 0.f;
+    int out_transposed = 0;          // out[b][t][co] (+ add[b % add_bmod][t][co])
+    const float* add = nullptr; int64_t add_bstride = 0; int add_bmod = 0;
+    int B = 1;
+    // transposed convolution (polyphase): stride u > 1
+    int tr_stride = 1; int tr_pad = 0; int tr_k = 0;
+};
+int launch_conv1d(const ConvArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+int launch_rmsnorm_mod(const float* h, const float* w, const float* shift, const float* scale, int mod_ld,
+                       int rows, int D, int T, float eps, Planes out, hipStream_t st);
+int launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps, float* out32, Planes outp,
+                     hipStream_t st);
+int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st);
+int launch_planes_to_f32(Planes in, int64_t n, float* out, hipStream_t st);
+int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias,
+                     int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st);
+int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* W,
+                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st);
+int launch_mean_rows(const float* x, int B, int L, int D, float* out, hipStream_t st);
+int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, float* out, hipStream_t st);
+int launch_pool_add(const float* a, const float* b, int B, int C, int T_in, float* out, hipStream_t st);
+int launch_transpose_bct_btc(const float* in, int B, int C, int T_in, int T_out, float* out, hipStream_t st);
+int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                       int rows, int D, int T, int C, float eps, float* out, hipStream_t st);
+int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_scale, const float* dt_table, const int* step,
+                     float dt_val, int has_uncond, hipStream_t st);
+int launch_router(const float* cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
+                  const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
+                  float* ma, float* lc_out, hipStream_t st);
+int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st);
+int launch_router_top1(const float* logits, const float* gumbel, int N, int E, int* idx, hipStream_t st);
+int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
+                       const int* step, int block, int gate, hipStream_t st);
+int launch_rows_dot(const float* x, const float* W, const float* bias, int N, int D, int E, float* out, hipStream_t st);
+int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, float* mean, float* rstd, hipStream_t st);
+int launch_softmax_rows_t(const float* s, int B, int R, int Ccols, float* out_t, hipStream_t st);
+int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, int reset, hipStream_t st);
+int launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// per-kernel-class HIP-event timing (bench.py roofline): 0 = gemm, 1 = attention, 2 = conv
+// ---------------------------------------------------------------------------
+void prof_start(int cls, double flops, hipStream_t st);
+void prof_stop(int cls, hipStream_t st);
+struct ProfScope {
+    int cls; hipStream_t st;
+    ProfScope(int c, double flops, hipStream_t s) : cls(c), st(s) { prof_start(c, flops, s); }
+    ~ProfScope() { prof_stop(cls, st); }
+};

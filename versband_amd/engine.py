@@ -1,0 +1,372 @@
+"""Python host side over the C ABI: device context, DiT engine, conv-net programs.
+
+torch is used for device memory, streams and checkpoint tensors only; every
+compute step of the hot path is a call into libversband_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import pack
+from .synth import DiTConfig, HifiGanConfig, VAEConfig
+
+Tensor = torch.Tensor
+
+
+def _require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise L.VersbandError("versband_amd runs on an MI355X only: no HIP device is visible (there is no CPU fallback)")
+    return device
+
+
+class Context:
+    """One vb_ctx per (process, device) - mirrors the reference's one process per GPU."""
+
+    def __init__(self, device="cuda:0"):
+        self.device = _require_gpu(device)
+        self.lib = L.load()
+        self.handle = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        torch.cuda.set_device(idx)
+        L.check(self.lib.vb_ctx_create(idx, C.byref(self.handle)), "vb_ctx_create")
+        self._keep: List[object] = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.vb_ctx_destroy(self.handle)
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# DiT
+# ---------------------------------------------------------------------------
+
+
+class DiTEngine:
+    """TxtFlagLargeImprovedDiTV2 (vocal2music_moe.py:477-520) + CFMSampler hot loop on the GPU.
+
+    precision "bf16"  : plain bf16 MFMA operands (production / benchmark)
+    precision "split" : bf16x3 split operands (fp32-class, parity tests)"""
+
+    def __init__(self, ctx: Context, cfg: DiTConfig, state_dict: Dict[str, Tensor], precision: str = "bf16"):
+        assert precision in ("bf16", "split")
+        self.ctx, self.cfg, self.precision = ctx, cfg, precision
+        self.np = 2 if precision == "split" else 1
+        dev = ctx.device
+        self.packed = pack.pack_dit(state_dict, cfg, self.np, dev)
+        self.ccfg = L.DitConfig(cfg.in_channels, cfg.hidden_size, cfg.num_heads, cfg.depth, cfg.num_experts, cfg.ffn_hidden,
+                                cfg.context_dim, cfg.ori_dim, cfg.max_len, self.np, cfg.norm_eps)
+        w = L.DitWeights()
+        for name in L.TOP_FIELDS:
+            setattr(w, name, self.packed["top"][name].data_ptr())
+        for i, b in enumerate(self.packed["blocks"]):
+            for name in L.BLOCK_FIELDS:
+                setattr(w.blocks[i], name, b[name].data_ptr())
+        self.cw = w
+        L.check(ctx.lib.vb_dit_load(ctx.handle, C.byref(self.ccfg), C.byref(w)), "vb_dit_load")
+        self._ws: Optional[Tensor] = None
+        self._ws_key = None
+
+    # -- buffers -----------------------------------------------------------
+    def _workspace(self, B, nb, T, Lc) -> Tensor:
+        key = (B, nb, T, Lc)
+        if self._ws_key != key:
+            n = self.ctx.lib.vb_dit_workspace_bytes(C.byref(self.ccfg), B, nb, T, Lc)
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.ctx.device)
+            self._ws_key = key
+        return self._ws
+
+    # -- API ---------------------------------------------------------------
+    def precompute_cond(self, t5: Tensor, midi: Tensor, beats: Tensor, T: int) -> dict:
+        """t5 [nb*B, L, ori] (cond rows then uncond rows), midi/beats [B,1,T_mel] or [B,T_mel] int64."""
+        dev = self.ctx.device
+        t5 = t5.to(dev, torch.float32).contiguous()
+        midi = midi.to(dev, torch.int64).reshape(midi.shape[0], -1).contiguous()
+        beats = beats.to(dev, torch.int64).reshape(beats.shape[0], -1).contiguous()
+        B, T_mel = midi.shape
+        Beff, Lc, _ = t5.shape
+        nb = Beff // B
+        assert nb * B == Beff and nb in (1, 2)
+        if midi.min() < 0 or midi.max() >= 130 or beats.min() < 0 or beats.max() >= 3:
+            raise IndexError("midi/beats index out of range of the embedding tables (130 / 3 rows)")
+        n = self.ctx.lib.vb_dit_cond_bytes(C.byref(self.ccfg), B, nb, T, Lc)
+        cond = torch.empty(n, dtype=torch.uint8, device=dev)
+        ws = self._workspace(B, nb, T, Lc)
+        L.check(self.ctx.lib.vb_dit_precompute_cond(self.ctx.handle, L.ptr(t5), L.ptr(midi), L.ptr(beats), B, nb, T, T_mel, Lc,
+                                                    L.ptr(cond), L.ptr(ws), L.stream_ptr()), "vb_dit_precompute_cond")
+        return {"buf": cond, "B": B, "nb": nb, "T": T, "L": Lc}
+
+    def _noise_struct(self, noise, seed, clip_base, nfe):
+        ns = L.Noise()
+        keep = None
+        if noise is not None:
+            g1, g2, g3 = [t.to(self.ctx.device, torch.float32).contiguous() for t in noise]
+            ns.g1, ns.g2, ns.g3 = g1.data_ptr(), g2.data_ptr(), g3.data_ptr()
+            keep = (g1, g2, g3)
+        ns.seed, ns.clip_base, ns.nfe = seed, clip_base, nfe
+        return ns, keep
+
+    def forward(self, x: Tensor, t_idx: Tensor, cond: dict, noise=None, seed: int = 0, clip_base: int = 0, nfe: int = 0,
+                return_routes: bool = False):
+        """x [B,C,T] f32, t_idx int64 [nb*B]; noise = (g1 [depth,rows,2], g2 [depth,rows,E], g3 [depth,rows,E]) Gumbel
+        draws or None -> v [nb*B, C, T] (+ routes int32 [depth,2,rows])."""
+        dev = self.ctx.device
+        B, nb, T, Lc = cond["B"], cond["nb"], cond["T"], cond["L"]
+        x = x.to(dev, torch.float32).contiguous()
+        t_idx = t_idx.to(dev, torch.int64).contiguous()
+        assert x.shape == (B, self.cfg.in_channels, T) and t_idx.numel() == nb * B
+        v = torch.empty(nb * B, self.cfg.in_channels, T, dtype=torch.float32, device=dev)
+        routes = torch.empty(self.cfg.depth, 2, nb * B * T, dtype=torch.int32, device=dev) if return_routes else None
+        ns, keep = self._noise_struct(noise, seed, clip_base, nfe)
+        ws = self._workspace(B, nb, T, Lc)
+        L.check(self.ctx.lib.vb_dit_forward(self.ctx.handle, L.ptr(x), L.ptr(t_idx), L.ptr(cond["buf"]), C.byref(ns), B, nb, T, Lc,
+                                            L.ptr(v), L.ptr(routes), L.ptr(ws), L.stream_ptr()), "vb_dit_forward")
+        return (v, routes) if return_routes else v
+
+    def sample_cfg(self, x0: Tensor, cond: dict, t_idx_table: Sequence[int], dt_table: Sequence[float], scale: float,
+                   noise=None, seed: int = 0, clip_base: int = 0, return_traj: bool = False):
+        """n Euler steps with classifier-free guidance; x0 [B,C,T] is not modified."""
+        dev = self.ctx.device
+        B, nb, T, Lc = cond["B"], cond["nb"], cond["T"], cond["L"]
+        x = x0.to(dev, torch.float32).contiguous().clone()
+        n = len(t_idx_table)
+        tt = (C.c_int64 * n)(*[int(v) for v in t_idx_table])
+        dd = (C.c_float * n)(*[float(v) for v in dt_table])
+        traj = torch.empty(n + 1, *x.shape, dtype=torch.float32, device=dev) if return_traj else None
+        ns, keep = self._noise_struct(noise, seed, clip_base, 0)
+        ws = self._workspace(B, nb, T, Lc)
+        L.check(self.ctx.lib.vb_sample_cfg(self.ctx.handle, L.ptr(x), L.ptr(cond["buf"]), B, nb, T, Lc, n, tt, dd, float(scale),
+                                           C.byref(ns), L.ptr(traj), L.ptr(ws), L.stream_ptr()), "vb_sample_cfg")
+        torch.cuda.current_stream().synchronize()   # host tables (tt, dd) must outlive the async copies
+        return (x, traj) if return_traj else x
+
+
+# ---------------------------------------------------------------------------
+# conv nets
+# ---------------------------------------------------------------------------
+
+
+class NetBuilder:
+    """Flattens a conv network into the vb_net_op list executed by the C++ runtime."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops: List[L.NetOp] = []
+        self.bufs: List[Tuple[int, int, int]] = []
+        self.free: Dict[Tuple[int, int, int], List[int]] = {}
+        self.keep: List[Tensor] = []
+
+    def buf(self, channels: int, tmul: int, square: bool = False) -> int:
+        key = (channels, tmul, int(square))
+        if self.free.get(key):
+            return self.free[key].pop()
+        self.bufs.append(key)
+        return len(self.bufs) - 1
+
+    def release(self, b: int):
+        if b >= 0:
+            self.free.setdefault(self.bufs[b], []).append(b)
+
+    def _t(self, t: Optional[Tensor]):
+        if t is None:
+            return None
+        t = t.to(self.device, torch.float32).contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def gn_stats(self, x: int, channels: int, groups: int = 32) -> int:
+        st = self.buf(2 * groups, 1)
+        op = L.NetOp(kind=L.OP_GN_STATS, x=x, out=-1, res=-1, stats=st, w_buf=-1, Ci=channels, gn_groups=groups)
+        self.ops.append(op)
+        return st
+
+    def softmax_t(self, x: int, out: int):
+        self.ops.append(L.NetOp(kind=L.OP_SOFTMAX_T, x=x, out=out, res=-1, stats=-1, w_buf=-1))
+
+    def conv(self, x: int, out: int, Ci: int, Co: int, w: Optional[Tensor] = None, bias: Optional[Tensor] = None, k: int = 1,
+             dil: int = 1, pad: int = 0, res: int = -1, stats: int = -1, gamma=None, beta_gn=None, in_act=L.ACT_NONE,
+             in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
+             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32):
+        op = L.NetOp(kind=L.OP_CONV, x=x, out=out, res=res, stats=stats, w_buf=w_buf, w=self._t(w), bias=self._t(bias),
+                     gn_gamma=self._t(gamma), gn_beta=self._t(beta_gn), Ci=Ci, Co=Co, ksize=k, dil=dil, pad=pad,
+                     upsample2=upsample2, in_act=in_act, out_act=out_act, out_transposed=out_transposed, tr_stride=tr_stride,
+                     tr_pad=tr_pad, tr_k=tr_k, gn_groups=groups, in_slope=in_slope, out_slope=out_slope, alpha=alpha, beta=beta,
+                     acc_scale=acc_scale)
+        self.ops.append(op)
+
+
+class ConvNet:
+    def __init__(self, ctx: Context, which: int, nb: NetBuilder, in_ch: int, out_ch: int, out_tmul: int):
+        self.ctx, self.which, self.nb = ctx, which, nb
+        self.in_ch, self.out_ch, self.out_tmul = in_ch, out_ch, out_tmul
+        ops = (L.NetOp * len(nb.ops))(*nb.ops)
+        bufs = (L.BufDesc * max(1, len(nb.bufs)))(*[L.BufDesc(*b) for b in nb.bufs])
+        L.check(ctx.lib.vb_net_load(ctx.handle, which, ops, len(nb.ops), bufs, len(nb.bufs), in_ch, out_ch, out_tmul), "vb_net_load")
+        self._ws = None
+        self._ws_key = None
+
+    def _workspace(self, B, T):
+        if self._ws_key != (B, T):
+            n = self.ctx.lib.vb_net_workspace_bytes(self.ctx.handle, self.which, B, T)
+            self._ws = torch.empty(max(n, 256), dtype=torch.uint8, device=self.ctx.device)
+            self._ws_key = (B, T)
+        return self._ws
+
+    def run(self, x: Tensor) -> Tensor:
+        x = x.to(self.ctx.device, torch.float32).contiguous()
+        B, Cin, T = x.shape
+        assert Cin == self.in_ch, (Cin, self.in_ch)
+        out = torch.empty(B, self.out_ch, T * self.out_tmul, dtype=torch.float32, device=self.ctx.device)
+        ws = self._workspace(B, T)
+        fn = self.ctx.lib.vb_vae_decode if self.which == L.NET_VAE else self.ctx.lib.vb_hifigan_forward
+        L.check(fn(self.ctx.handle, L.ptr(x), B, T, L.ptr(out), L.ptr(ws), L.stream_ptr()), "conv net run")
+        return out
+
+
+def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float = 1.0) -> ConvNet:
+    """AutoencoderKL.decode (autoencoder1d.py:55-58) + Decoder1D.forward (:480-512) as an op list.
+    The structure (levels, shortcut convs, attention blocks, which level upsamples) is read off the
+    key names, exactly what load_state_dict would accept."""
+    nb = NetBuilder(ctx.device)
+    g = sd
+
+    def cw(name):
+        return pack.pack_conv(g[name + ".weight"]), g[name + ".bias"]
+
+    def resblock(x, cin, tm, p):
+        cout = g[p + "conv1.weight"].shape[0]
+        st1 = nb.gn_stats(x, cin)
+        t1 = nb.buf(cout, tm)
+        w, b = cw(p + "conv1")
+        nb.conv(x, t1, cin, cout, w, b, k=3, pad=1, stats=st1, gamma=g[p + "norm1.weight"], beta_gn=g[p + "norm1.bias"],
+                in_act=L.ACT_GN_SWISH)
+        nb.release(st1)
+        st2 = nb.gn_stats(t1, cout)
+        sc = x
+        if (p + "nin_shortcut.weight") in g:
+            sc = nb.buf(cout, tm)
+            w, b = cw(p + "nin_shortcut")
+            nb.conv(x, sc, cin, cout, w, b)
+        out = nb.buf(cout, tm)
+        w, b = cw(p + "conv2")
+        nb.conv(t1, out, cout, cout, w, b, k=3, pad=1, res=sc, stats=st2, gamma=g[p + "norm2.weight"], beta_gn=g[p + "norm2.bias"],
+                in_act=L.ACT_GN_SWISH)
+        nb.release(st2); nb.release(t1)
+        if sc != x:
+            nb.release(sc)
+        nb.release(x)
+        return out, cout
+
+    def attnblock(x, c, tm, p):
+        st = nb.gn_stats(x, c)
+        q, k, vT = nb.buf(c, tm), nb.buf(c, tm), nb.buf(c, tm)
+        gam, bet = g[p + "norm.weight"], g[p + "norm.bias"]
+        for name, dst, tr in (("q", q, 0), ("k", k, 0), ("v", vT, 1)):
+            w, b = cw(p + name)
+            nb.conv(x, dst, c, c, w, b, stats=st, gamma=gam, beta_gn=bet, in_act=L.ACT_GN, out_transposed=tr)
+        s = nb.buf(0, tm, True)
+        nb.conv(k, s, c, -1, w_buf=q, acc_scale=float(int(c) ** (-0.5)))      # w[b,i,j] = sum_c q[c,i] k[c,j] * C^-0.5
+        pT = nb.buf(0, tm, True)
+        nb.softmax_t(s, pT)
+        a = nb.buf(c, tm)
+        nb.conv(pT, a, -1, c, w_buf=vT)                                        # h[c,i] = sum_j v[c,j] P[i,j]
+        out = nb.buf(c, tm)
+        w, b = cw(p + "proj_out")
+        nb.conv(a, out, c, c, w, b, res=x)
+        for t in (st, q, k, vT, s, pT, a, x):
+            nb.release(t)
+        return out
+
+    zc = g["post_quant_conv.weight"].shape[1]
+    h = nb.buf(g["post_quant_conv.weight"].shape[0], 1)
+    w, b = cw("post_quant_conv")
+    nb.conv(L.BUF_INPUT, h, zc, g["post_quant_conv.weight"].shape[0], w, b, acc_scale=1.0 / float(scale_factor))
+    w, b = cw("decoder.conv_in")
+    c = g["decoder.conv_in.weight"].shape[0]
+    kk = g["decoder.conv_in.weight"].shape[2]
+    h2 = nb.buf(c, 1)
+    nb.conv(h, h2, g["decoder.conv_in.weight"].shape[1], c, w, b, k=kk, pad=kk // 2)
+    nb.release(h)
+    h, tm = h2, 1
+    h, c = resblock(h, c, tm, "decoder.mid.block_1.")
+    h = attnblock(h, c, tm, "decoder.mid.attn_1.")
+    h, c = resblock(h, c, tm, "decoder.mid.block_2.")
+    levels = sorted({int(k.split(".")[2]) for k in g if k.startswith("decoder.up.")})
+    for lvl in reversed(levels):
+        nblk = len({int(k.split(".")[4]) for k in g if k.startswith(f"decoder.up.{lvl}.block.")})
+        for bi in range(nblk):
+            h, c = resblock(h, c, tm, f"decoder.up.{lvl}.block.{bi}.")
+            if f"decoder.up.{lvl}.attn.{bi}.norm.weight" in g:
+                h = attnblock(h, c, tm, f"decoder.up.{lvl}.attn.{bi}.")
+        if f"decoder.up.{lvl}.upsample.conv.weight" in g:
+            w, b = cw(f"decoder.up.{lvl}.upsample.conv")
+            h2 = nb.buf(c, tm * 2)
+            nb.conv(h, h2, c, c, w, b, k=3, pad=1, upsample2=1)
+            nb.release(h)
+            h, tm = h2, tm * 2
+    st = nb.gn_stats(h, c)
+    w, b = cw("decoder.conv_out")
+    co, kk = g["decoder.conv_out.weight"].shape[0], g["decoder.conv_out.weight"].shape[2]
+    nb.conv(h, L.BUF_OUTPUT, c, co, w, b, k=kk, pad=kk // 2, stats=st, gamma=g["decoder.norm_out.weight"],
+            beta_gn=g["decoder.norm_out.bias"], in_act=L.ACT_GN_SWISH)
+    return ConvNet(ctx, L.NET_VAE, nb, zc, co, tm)
+
+
+def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict) -> ConvNet:
+    """HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) as an op list; fully
+    driven by the vocoder's config.yaml keys."""
+    nb = NetBuilder(ctx.device)
+
+    def wt(name):
+        if name + ".weight" in sd:
+            return sd[name + ".weight"].float()
+        return pack.fold_weight_norm(sd[name + ".weight_g"].float(), sd[name + ".weight_v"].float())
+
+    nk = len(hp["resblock_kernel_sizes"])
+    c0 = hp["upsample_initial_channel"]
+    wpre = wt("conv_pre")
+    x = nb.buf(c0, 1)
+    nb.conv(L.BUF_INPUT, x, wpre.shape[1], c0, pack.pack_conv(wpre), sd["conv_pre.bias"], k=7, pad=3)
+    tm, ch = 1, c0
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        cin, ch = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        tm *= u
+        xu = nb.buf(ch, tm)
+        nb.conv(x, xu, cin, ch, pack.pack_conv_transpose(wt(f"ups.{i}"), u), sd[f"ups.{i}.bias"], in_act=L.ACT_LRELU, in_slope=0.1,
+                tr_stride=u, tr_pad=(k - u) // 2, tr_k=k)
+        nb.release(x)
+        xs = nb.buf(ch, tm)
+        for j, (rk, rd) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            n = i * nk + j
+            r = xu
+            for m, d in enumerate(rd):
+                last = m == len(rd) - 1
+                dst = xs if last else nb.buf(ch, tm)
+                al, be = (1.0 / nk, 0.0 if j == 0 else 1.0) if last else (1.0, 0.0)
+                if hp["resblock"] == "1":
+                    t1 = nb.buf(ch, tm)
+                    nb.conv(r, t1, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs1.{m}")), sd[f"resblocks.{n}.convs1.{m}.bias"], k=rk,
+                            dil=d, pad=(rk * d - d) // 2, in_act=L.ACT_LRELU, in_slope=0.1)
+                    nb.conv(t1, dst, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs2.{m}")), sd[f"resblocks.{n}.convs2.{m}.bias"], k=rk,
+                            pad=(rk - 1) // 2, in_act=L.ACT_LRELU, in_slope=0.1, res=r, alpha=al, beta=be)
+                    nb.release(t1)
+                else:
+                    nb.conv(r, dst, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs.{m}")), sd[f"resblocks.{n}.convs.{m}.bias"], k=rk,
+                            dil=d, pad=(rk * d - d) // 2, in_act=L.ACT_LRELU, in_slope=0.1, res=r, alpha=al, beta=be)
+                if r != xu:
+                    nb.release(r)
+                r = dst
+        nb.release(xu)
+        x = xs
+    wpost = wt("conv_post")
+    nb.conv(x, L.BUF_OUTPUT, ch, wpost.shape[0], pack.pack_conv(wpost), sd["conv_post.bias"], k=7, pad=3, in_act=L.ACT_LRELU,
+            in_slope=0.01, out_act=L.ACT_TANH)
+    return ConvNet(ctx, L.NET_VOCODER, nb, wpre.shape[1], wpost.shape[0], tm)

@@ -1,0 +1,428 @@
+"""Host-side mirror of the reference's operator API for the inference path.
+
+Same class names, constructor params (configs/vocal2music.yaml), method names,
+argument meaning and error behaviour as the reference modules they stand in for,
+so ``scripts/test_final.py``-style callers run unchanged; the compute underneath
+is libversband_hip.so (versband_amd.engine).  The ``ldm.*`` / ``vocoder.*``
+packages at the repo root re-export these under the reference's dotted paths so
+``instantiate_from_config`` resolves the YAML ``target`` strings as-is.
+"""
+from __future__ import annotations
+
+import glob
+import importlib
+import os
+import re
+import warnings
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import yaml
+
+from . import prng
+from .synth import DiTConfig, HifiGanConfig, VAEConfig
+
+Tensor = torch.Tensor
+
+# ---------------------------------------------------------------------------
+# config / factory  (ldm/util.py:110-125, OmegaConf stand-in)
+# ---------------------------------------------------------------------------
+
+
+class AttrDict(dict):
+    """dict with attribute access, enough of OmegaConf's DictConfig for this path."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(o):
+        if isinstance(o, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in o.items()})
+        if isinstance(o, list):
+            return [AttrDict.wrap(v) for v in o]
+        return o
+
+
+def load_config(path: str) -> AttrDict:
+    with open(path) as f:
+        return AttrDict.wrap(yaml.safe_load(f))
+
+
+def get_obj_from_str(string: str, reload: bool = False):
+    module, cls = string.rsplit(".", 1)
+    m = importlib.import_module(module)
+    if reload:
+        importlib.reload(m)
+    return getattr(m, cls)
+
+
+def instantiate_from_config(config, reload: bool = False):
+    """ldm/util.py:110-117: ``target`` dotted path + ``params`` kwargs."""
+    if "target" not in config:
+        if config == "__is_first_stage__" or config == "__is_unconditional__":
+            return None
+        raise KeyError("Expected key `target` to instantiate.")
+    return get_obj_from_str(config["target"], reload=reload)(**config.get("params", dict()))
+
+
+# ---------------------------------------------------------------------------
+# network holders
+# ---------------------------------------------------------------------------
+
+
+class TxtFlagLargeImprovedDiTV2:
+    """Parameter holder for vocal2music_moe.py:477-520 (same ctor signature)."""
+
+    def __init__(self, in_channels, context_dim, hidden_size=1152, depth=28, num_heads=16, max_len=1000, num_experts=4,
+                 ori_dim=1024):
+        # ori_dim is accepted and ignored exactly like the reference ctor: T5 width stays 1024
+        self.cfg = DiTConfig(in_channels=in_channels, ori_dim=1024, context_dim=context_dim, hidden_size=hidden_size,
+                             num_heads=num_heads, depth=depth, max_len=max_len, num_experts=num_experts)
+        if context_dim != hidden_size:
+            raise ValueError("context_dim must equal hidden_size (cap_embedder / Attention y_dim, vocal2music_moe.py:367-373)")
+        self.in_channels = self.out_channels = in_channels
+
+
+class AutoencoderKL:
+    """ldm/models/autoencoder1d.py:14-58 (decode side)."""
+
+    def __init__(self, embed_dim, ddconfig, lossconfig=None, ckpt_path=None, ignore_keys=(), image_key="image", monitor=None):
+        assert ddconfig["double_z"]
+        self.embed_dim = embed_dim
+        self.ddconfig = dict(ddconfig)
+        self.image_key = image_key
+        self.state: Dict[str, Tensor] = {}
+        self.net = None
+        if ckpt_path is not None:
+            if os.path.exists(ckpt_path):
+                self.init_from_ckpt(ckpt_path, ignore_keys)
+            else:
+                warnings.warn(f"AutoencoderKL ckpt_path {ckpt_path} not found; weights must come from the CFM checkpoint")
+
+    def init_from_ckpt(self, path, ignore_keys=()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        self.load_state_dict(sd)
+
+    def load_state_dict(self, sd, strict=False):
+        self.state = {k: v for k, v in sd.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+        self.net = None
+
+    def encode(self, x):
+        raise NotImplementedError("the VAE encoder is outside the accelerated inference path (SURVEY §8f N2)")
+
+
+class DiffusionWrapper:
+    """ldm/models/diffusion/ddpm.py:1396-1446 ('hybrid' conditioning only)."""
+
+    def __init__(self, diff_model_config, conditioning_key):
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+        assert conditioning_key in (None, "concat", "crossattn", "hybrid", "adm", "film")
+
+
+class FrozenTextVocalEmbedder:
+    """ldm/modules/encoders/modules.py:194-233 boundary: returns {'caption': [B,L,1024] f32, 'acoustic', 'name'}.
+    The FLAN-T5 encoder is upstream of the accelerated path; captions given as
+    pre-computed embeddings pass through, strings get seeded dummy embeddings (BASELINE: dummy T5)."""
+
+    def __init__(self, version="google/flan-t5-large", device="cuda", max_length=77, freeze=True, **kw):
+        self.version, self.max_length, self.device = version, max_length, device
+        self.width = 1024
+
+    def to(self, device):
+        self.device = device
+        return self
+
+    def _embed_text(self, caps: List[str]) -> Tensor:
+        out = []
+        for c in caps:
+            ks = prng.key_seed(20240921, "t5:" + c)
+            out.append(torch.from_numpy(prng.normal(ks, self.max_length * self.width).reshape(self.max_length, self.width)))
+        return torch.stack(out)
+
+    def encode(self, c):
+        return self(c)
+
+    def __call__(self, c):
+        cap = c["caption"]
+        if not torch.is_tensor(cap):
+            cap = self._embed_text(list(cap))
+        return {"caption": cap.float(), "acoustic": c["acoustic"], "name": c.get("name")}
+
+
+# ---------------------------------------------------------------------------
+# CFM model shell  (ldm/models/diffusion/cfm1_audio.py:31-36 over ddpm_audio.py LatentDiffusion_audio)
+# ---------------------------------------------------------------------------
+
+
+class CFM:
+    def __init__(self, unet_config=None, first_stage_config=None, cond_stage_config=None, timesteps=1000, mel_dim=80,
+                 mel_length=848, channels=0, conditioning_key=None, scale_by_std=False, scale_factor=1.0, precision="bf16",
+                 **ignored):
+        self.num_timesteps = timesteps
+        self.mel_dim, self.mel_length, self.channels = mel_dim, mel_length, channels
+        self.sigma_min = 1e-4
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.first_stage_model = instantiate_from_config(first_stage_config)
+        self.cond_stage_model = instantiate_from_config(cond_stage_config)
+        self.cond_stage_forward = None
+        self.scale_factor = torch.tensor(float(scale_factor))
+        self.precision = precision
+        self.device = torch.device("cpu")
+        self._dit_state: Dict[str, Tensor] = {}
+        self._ctx = None
+        self._dit = None
+        self._cond_cache: Dict[int, Any] = {}
+
+    # -- checkpoint (scripts/test_final.py:143) ----------------------------
+    def load_state_dict(self, sd: Dict[str, Tensor], strict: bool = False):
+        dp, fp = "model.diffusion_model.", "first_stage_model."
+        dit = {k[len(dp):]: v for k, v in sd.items() if k.startswith(dp)}
+        if dit:
+            self._dit_state = dit
+            self._dit = None
+        vae = {k[len(fp):]: v for k, v in sd.items() if k.startswith(fp)}
+        if vae:
+            self.first_stage_model.load_state_dict(vae)
+        if "scale_factor" in sd:
+            self.scale_factor = sd["scale_factor"].detach().float().cpu().reshape(())
+        if strict:
+            from .synth import dit_shapes
+            missing = [k for k in dit_shapes(self.model.diffusion_model.cfg) if k not in dit]
+            if missing:
+                raise RuntimeError(f"Missing key(s) in state_dict: {missing[:5]} ...")
+        return [], []
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    # -- engines -----------------------------------------------------------
+    def _context(self):
+        from .engine import Context
+        if self._ctx is None or self._ctx.device != self.device:
+            self._ctx = Context(self.device)
+            self._dit = None
+            self.first_stage_model.net = None
+        return self._ctx
+
+    def dit_engine(self):
+        from .engine import DiTEngine
+        ctx = self._context()
+        if self._dit is None:
+            if not self._dit_state:
+                raise RuntimeError("CFM: no DiT weights loaded (load_state_dict first)")
+            self._dit = DiTEngine(ctx, self.model.diffusion_model.cfg, self._dit_state, precision=self.precision)
+        return self._dit
+
+    def vae_net(self):
+        from .engine import build_vae_decoder
+        ctx = self._context()
+        fs = self.first_stage_model
+        if fs.net is None:
+            if not fs.state:
+                raise RuntimeError("CFM: no first_stage_model weights loaded")
+            fs.net = build_vae_decoder(ctx, fs.state, scale_factor=float(self.scale_factor))
+        return fs.net
+
+    # -- reference API -----------------------------------------------------
+    def get_learned_conditioning(self, c):
+        """ddpm_audio.py:182-193."""
+        if hasattr(self.cond_stage_model, "encode") and callable(self.cond_stage_model.encode):
+            return self.cond_stage_model.encode(c)
+        return self.cond_stage_model(c)
+
+    def _precompute(self, conds: List[dict], T: int):
+        key = tuple(id(c) for c in conds) + (T,)
+        hit = self._cond_cache.get(key)
+        if hit is not None:
+            return hit[0]
+        ac = conds[0]["acoustic"]
+        t5 = torch.cat([c["caption"].float().to(self.device) for c in conds], dim=0)
+        pc = self.dit_engine().precompute_cond(t5, ac["midi"], ac["beats"], T)
+        self._cond_cache = {key: (pc, conds)}     # single entry: holds the cond dicts alive so ids stay unique
+        return pc
+
+    @torch.no_grad()
+    def apply_model(self, x_noisy, t, cond, return_ids=False):
+        """ddpm_audio.py:443-469: one conditional evaluation -> (v, lb_loss)."""
+        if not isinstance(cond, dict):
+            raise NotImplementedError("only the hybrid dict conditioning of configs/vocal2music.yaml is supported")
+        pc = self._precompute([cond], x_noisy.shape[-1])
+        v = self.dit_engine().forward(x_noisy, t, pc, seed=int(torch.initial_seed()) & 0xFFFFFFFF)
+        return v, torch.zeros((), device=v.device)
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        """ddpm_audio.py:379-392: z / scale_factor -> AutoencoderKL.decode."""
+        return self.vae_net().run(z)
+
+
+# ---------------------------------------------------------------------------
+# sampler  (ldm/models/diffusion/cfm1_audio_sampler.py)
+# ---------------------------------------------------------------------------
+
+
+def euler_tables(timesteps: int, t_start: Optional[int] = None):
+    """t_span = linspace(0,1,timesteps) (:108), optional t_span[t_start:] (:110-111); per step the solver's dt
+    (float32, accumulated like torchdyn's fixed-step loop) and the integer index Wrapper_cfg feeds the DiT:
+    trunc(float32(t)*1000) (cfm1_audio.py:156 - SURVEY Q3)."""
+    t_span = torch.linspace(0, 1, timesteps)
+    if t_start is not None:
+        t_span = t_span[t_start:]
+    idx, dts = [], []
+    t = t_span[0]
+    for k in range(len(t_span) - 1):
+        dt = t_span[k + 1] - t
+        idx.append(int(torch.tensor([t * 1000]).long().item()))
+        dts.append(float(dt))
+        t = t + dt
+    return idx, dts
+
+
+class CFMSampler(object):
+    def __init__(self, model, num_timesteps, schedule="linear", **kwargs):
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.num_timesteps = num_timesteps
+        self.schedule = schedule
+
+    def stochastic_encode(self, x_start, t, noise=None):
+        """:41-46."""
+        x0 = torch.randn_like(x_start) if noise is None else noise
+        tu = 1 - t.unsqueeze(1).unsqueeze(1).float() / self.num_timesteps
+        return tu * x_start + (1.0 - (1 - self.model.sigma_min) * tu) * x0
+
+    def _shape(self, shape, batch_size):
+        if shape is None:
+            if self.model.channels > 0:
+                shape = (batch_size, self.model.channels, self.model.mel_dim, self.model.mel_length)
+            else:
+                shape = (batch_size, self.model.mel_dim, self.model.mel_length)
+            return tuple(shape)
+        if len(shape) == 3:
+            raise NotImplementedError("2-D latents are not part of the vocal2music path")
+        C, T = shape
+        return (batch_size, C, T)
+
+    @torch.no_grad()
+    def sample_cfg(self, cond, unconditional_guidance_scale, unconditional_conditioning, batch_size=16, timesteps=None, shape=None,
+                   x_latent=None, t_start=None, gumbel_noise=None, seed=None, clip_base=0, **kwargs):
+        """:87-116.  Extra kwargs (S=, x_T=, verbose=) are tolerated and ignored like the reference does
+        (SURVEY Q1/Q2).  gumbel_noise/seed/clip_base are additions: injected router noise for parity, or the
+        (seed, global clip index) that keys the on-device counter-based draws."""
+        shape = self._shape(shape, batch_size)
+        idx, dts = euler_tables(25 if timesteps is None else timesteps, t_start)
+        dev = self.model.device
+        x0 = torch.randn(shape, device=dev) if x_latent is None else x_latent
+        conds = [cond] if unconditional_conditioning is None else [cond, unconditional_conditioning]
+        pc = self.model._precompute(conds, shape[-1])
+        if seed is None:
+            seed = int(torch.initial_seed()) & 0xFFFFFFFF
+        x, traj = self.model.dit_engine().sample_cfg(x0, pc, idx, dts, float(unconditional_guidance_scale), noise=gumbel_noise,
+                                                     seed=seed, clip_base=clip_base, return_traj=True)
+        return traj[-1], traj
+
+    @torch.no_grad()
+    def sample(self, cond, batch_size=16, timesteps=None, shape=None, x_latent=None, t_start=None, **kwargs):
+        """:49-80 (no guidance)."""
+        return self.sample_cfg(cond, 1.0, None, batch_size=batch_size, timesteps=timesteps, shape=shape, x_latent=x_latent,
+                               t_start=t_start, **kwargs)
+
+
+# ---------------------------------------------------------------------------
+# vocoder  (vocoder/hifigan/hifigan.py:7-43, utils/commons/{hparams,ckpt_utils}.py)
+# ---------------------------------------------------------------------------
+
+
+def set_hparams(config_path: str) -> dict:
+    """utils/commons/hparams.py:25-133 reduced to what HifiGAN needs: yaml + base_config inheritance."""
+    def load(p, seen):
+        with open(p) as f:
+            hp = yaml.safe_load(f) or {}
+        out = {}
+        bases = hp.get("base_config", [])
+        if isinstance(bases, str):
+            bases = [bases]
+        for b in bases:
+            if b.startswith("."):
+                b = os.path.normpath(os.path.join(os.path.dirname(p), b))
+            if b not in seen and os.path.exists(b):
+                out.update(load(b, seen | {b}))
+        out.update({k: v for k, v in hp.items() if k != "base_config"})
+        return out
+    return load(config_path, {config_path})
+
+
+def load_ckpt_state(ckpt_base_dir: str, model_name: str = "model_gen") -> Dict[str, Tensor]:
+    """utils/commons/ckpt_utils.py:7-67: newest model_ckpt_steps_N.ckpt, state_dict[model_name] or 'model_name.'-prefixed keys."""
+    if os.path.isfile(ckpt_base_dir):
+        path = ckpt_base_dir
+    else:
+        paths = sorted(glob.glob(f"{ckpt_base_dir}/model_ckpt_steps_*.ckpt"),
+                       key=lambda x: -int(re.findall(r".*steps\_(\d+)\.ckpt", x)[0]))
+        assert len(paths) > 0, f"| ckpt not found in {ckpt_base_dir}."
+        path = paths[0]
+    sd = torch.load(path, map_location="cpu")["state_dict"]
+    if len([k for k in sd.keys() if "." in k]) > 0:
+        sd = {k[len(model_name) + 1:]: v for k, v in sd.items() if k.startswith(f"{model_name}.")}
+    else:
+        sd = sd[model_name]
+    return sd
+
+
+class HifiGAN:
+    def __init__(self, vocoder_ckpt, device=None):
+        base_dir = vocoder_ckpt
+        self.config = set_hparams(f"{base_dir}/config.yaml")
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.state = load_ckpt_state(base_dir, "model_gen")
+        self._net = None
+        self._ctx = None
+
+    def net(self):
+        from .engine import Context, build_hifigan
+        if self._net is None:
+            self._ctx = Context(self.device)
+            self._net = build_hifigan(self._ctx, self.state, self.config)
+        return self._net
+
+    def spec2wav(self, mel, **kwargs):
+        """mel [T,80] (numpy / cpu tensor) -> wav float32 numpy [T*hop]  (hifigan.py:20-30)."""
+        c = torch.as_tensor(np.asarray(mel) if not torch.is_tensor(mel) else mel, dtype=torch.float32).unsqueeze(0)
+        c = c.transpose(2, 1).contiguous()
+        return self.net().run(c).view(-1).cpu().numpy()
+
+    def spec2wav_batch(self, mel_bct: Tensor) -> Tensor:
+        """device-resident batched path: mel [B,80,T] -> wav [B, T*hop] (no host round trip)."""
+        return self.net().run(mel_bct).squeeze(1)
+
+    def __call__(self, mel):
+        return self.spec2wav(mel)
+
+    def vocode(self, mel):
+        assert len(mel.shape) == 2
+        c = torch.as_tensor(np.asarray(mel) if not torch.is_tensor(mel) else mel, dtype=torch.float32).unsqueeze(0)
+        if c.shape[1] != 80:
+            c = c.transpose(2, 1)
+        return self.net().run(c.contiguous()).view(-1).cpu().numpy()
+
+
+def normalize_loudness(wav, target_loudness):
+    """scripts/test_final.py:342-347."""
+    rms = np.sqrt(np.mean(wav ** 2))
+    loudness = 20 * np.log10(rms)
+    gain = target_loudness - loudness
+    return wav * 10 ** (gain / 20)

@@ -1,0 +1,136 @@
+"""Checkpoint -> device layout packing (host plumbing, runs once at load).
+
+Takes the reference's ``state_dict`` tensors (SURVEY.md §8b key layout) and
+produces the packed tensors the HIP kernels read: bf16 hi/lo planes for MFMA
+GEMM weights, interleaved (w1,w3) rows for the fused SwiGLU epilogue, band
+slices of the frequency experts, [tap][Ci][Co] conv weights, polyphase
+ConvTranspose weights, folded weight-norm.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+
+Tensor = torch.Tensor
+
+
+def to_planes(w: Tensor, n_planes: int) -> Tensor:
+    """fp32 -> bf16 planes [n_planes, *w.shape]; plane 1 = bf16(w - float(plane 0))."""
+    w = w.float().contiguous()
+    hi = w.to(torch.bfloat16)
+    if n_planes == 1:
+        return hi.unsqueeze(0).contiguous()
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).contiguous()
+
+
+def planes_to_float(p: Tensor) -> Tensor:
+    return p.float().sum(dim=0)
+
+
+def pack_conv(w: Tensor) -> Tensor:
+    """Conv1d weight [Co,Ci,k] -> [k][Ci][Co] fp32."""
+    return w.float().permute(2, 1, 0).contiguous()
+
+
+def pack_conv_transpose(w: Tensor, stride: int) -> Tensor:
+    """ConvTranspose1d weight [Ci,Co,k] -> polyphase [stride][Kmax][Ci][Co]:
+    tap j of phase p holds W[:, :, p + stride*(Kmax-1-j)] (zero when that index >= k)."""
+    ci, co, k = w.shape
+    kmax = (k + stride - 1) // stride
+    out = torch.zeros(stride, kmax, ci, co, dtype=torch.float32, device=w.device)
+    for p in range(stride):
+        for j in range(kmax):
+            idx = p + stride * (kmax - 1 - j)
+            if idx < k:
+                out[p, j] = w[:, :, idx].float()
+    return out.contiguous()
+
+
+def fold_weight_norm(g: Tensor, v: Tensor) -> Tensor:
+    """weight_norm(dim=0): w = g * v / ||v|| (the reference never removes weight norm:
+    vocoder/hifigan/hifigan.py:15-18, so checkpoints carry weight_g / weight_v)."""
+    n = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+    return v * (g / n)
+
+
+def timestep_table(n: int = 1000, dim: int = 256, max_period: float = 10000.0) -> Tensor:
+    """Sinusoid rows for every integer diffusion index (TimestepEmbedder.timestep_embedding,
+    flag_large_dit_moe.py:110-128), computed on the CPU exactly like the reference does."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = torch.arange(n, dtype=torch.long)[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).contiguous()
+
+
+def rope_tables(head_dim: int, end: int, theta: float = 10000.0):
+    """cos/sin of precompute_freqs_cis (vocal2music_moe.py:436-475), CPU float32."""
+    freqs = 1.0 / (theta ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    ang = torch.outer(torch.arange(end, dtype=torch.float32), freqs).float()
+    return torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+
+
+def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, object]:
+    """-> {"top": {field: tensor}, "blocks": [{field: tensor}, ...]} matching vb_dit_weights."""
+    D, E, H = cfg.hidden_size, cfg.num_experts, cfg.ffn_hidden
+    band = D // E
+    g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
+    top: Dict[str, Tensor] = {}
+    top["t_freq_table"] = timestep_table().to(device)
+    top["t_mlp0_w"], top["t_mlp0_b"] = g("t_embedder.mlp.0.weight"), g("t_embedder.mlp.0.bias")
+    top["t_mlp2_w"], top["t_mlp2_b"] = g("t_embedder.mlp.2.weight"), g("t_embedder.mlp.2.bias")
+    top["adaln_w"] = torch.cat([g(f"blocks.{i}.adaLN_modulation.1.weight") for i in range(cfg.depth)]
+                               + [g("final_layer.adaLN_modulation.1.weight")]).contiguous()
+    top["adaln_b"] = torch.cat([g(f"blocks.{i}.adaLN_modulation.1.bias") for i in range(cfg.depth)]
+                               + [g("final_layer.adaLN_modulation.1.bias")]).contiguous()
+    top["hl_w"] = torch.cat([g(f"blocks.{i}.feed_forward.high_level_gating_network.weight") for i in range(cfg.depth)]).contiguous()
+    top["hl_b"] = torch.cat([g(f"blocks.{i}.feed_forward.high_level_gating_network.bias") for i in range(cfg.depth)]).contiguous()
+    top["proj_in_w"], top["proj_in_b"] = pack_conv(g("proj_in.weight")), g("proj_in.bias")
+    top["final_w"], top["final_b"] = g("final_layer.linear.weight"), g("final_layer.linear.bias")
+    cos, sin = rope_tables(cfg.head_dim, cfg.max_len)
+    top["rope_cos"], top["rope_sin"] = cos.to(device), sin.to(device)
+    top["midi_emb"], top["beats_emb"] = g("midi_embedding.weight"), g("beats_embedding.weight")
+    top["midi_conv_w"], top["midi_conv_b"] = pack_conv(g("midi_proj.0.weight")), g("midi_proj.0.bias")
+    top["beats_conv_w"], top["beats_conv_b"] = pack_conv(g("beats_proj.0.weight")), g("beats_proj.0.bias")
+    top["final_proj_w"], top["final_proj_b"] = pack_conv(g("final_proj.weight")), g("final_proj.bias")
+    top["c_emb0"], top["c_emb0_b"] = to_planes(g("c_embedder.mlp.0.weight"), 2), g("c_embedder.mlp.0.bias")
+    top["c_emb2"], top["c_emb2_b"] = to_planes(g("c_embedder.mlp.2.weight"), 2), g("c_embedder.mlp.2.bias")
+    top["c_ln_w"], top["c_ln_b"] = g("c_embedder.mlp.3.weight"), g("c_embedder.mlp.3.bias")
+    top["cap_ln_w"], top["cap_ln_b"] = g("cap_embedder.0.weight"), g("cap_embedder.0.bias")
+    top["cap_lin_w"], top["cap_lin_b"] = g("cap_embedder.1.weight"), g("cap_embedder.1.bias")
+    blocks: List[Dict[str, Tensor]] = []
+    for i in range(cfg.depth):
+        p = f"blocks.{i}."
+        b: Dict[str, Tensor] = {}
+        b["wqkv"] = to_planes(torch.cat([g(p + "attention.wq.weight"), g(p + "attention.wk.weight"), g(p + "attention.wv.weight")]), n_planes)
+        b["wo"] = to_planes(g(p + "attention.wo.weight"), n_planes)
+        w_in, b_in = g(p + "feed_forward.cross_attention.in_proj_weight"), g(p + "feed_forward.cross_attention.in_proj_bias")
+        b["wq_m"] = to_planes(w_in[:D], n_planes)
+        b["wk_m"], b["wv_m"] = to_planes(w_in[D:2 * D], 2), to_planes(w_in[2 * D:], 2)
+        b["bq_m"], b["bk_m"], b["bv_m"] = b_in[:D].contiguous(), b_in[D:2 * D].contiguous(), b_in[2 * D:].contiguous()
+        b["wo_m"] = to_planes(g(p + "feed_forward.cross_attention.out_proj.weight"), n_planes)
+        b["bo_m"] = g(p + "feed_forward.cross_attention.out_proj.bias")
+        w13, w2 = [], []
+        for grp in ("caption_experts", "acoustic_experts"):
+            for e in range(E):
+                q = f"{p}feed_forward.{grp}.{e}."
+                w13.append(torch.stack([g(q + "w1.weight"), g(q + "w3.weight")], dim=1).reshape(2 * H, D))
+                w2.append(g(q + "w2.weight"))
+        b["w13"], b["w2"] = to_planes(torch.stack(w13), n_planes), to_planes(torch.stack(w2), n_planes)
+        w13f, w2f = [], []
+        for e in range(E):
+            q = f"{p}feed_forward.freq_experts.{e}."
+            lo, hi = band * e, band * (e + 1)
+            w13f.append(torch.stack([g(q + "w1.weight")[:, lo:hi], g(q + "w3.weight")[:, lo:hi]], dim=1).reshape(2 * H, band))
+            w2f.append(g(q + "w2.weight")[lo:hi, :])
+        b["w13f"], b["w2f"] = to_planes(torch.stack(w13f), n_planes), to_planes(torch.stack(w2f), n_planes)
+        b["wky"], b["wvy"] = to_planes(g(p + "attention.wk_y.weight"), 2), to_planes(g(p + "attention.wv_y.weight"), 2)
+        b["attn_norm_w"], b["ffn_norm_w"] = g(p + "attention_norm.weight"), g(p + "ffn_norm.weight")
+        b["y_norm_w"] = g(p + "attention_y_norm.weight")
+        b["cross_w"] = torch.tanh(g(p + "attention.gate")).contiguous()
+        b["wcg"], b["bcg"] = g(p + "feed_forward.caption_gating_network.weight"), g(p + "feed_forward.caption_gating_network.bias")
+        b["wag"], b["bag"] = g(p + "feed_forward.acoustic_gating_network.weight"), g(p + "feed_forward.acoustic_gating_network.bias")
+        blocks.append(b)
+    return {"top": top, "blocks": blocks}
