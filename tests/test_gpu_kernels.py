@@ -21,8 +21,18 @@ def lib():
     return L.load()
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.cuda().contiguous()
+    """upload and KEEP the tensor alive: a temporary would be freed (and its block reused by the next
+    upload) before the asynchronous kernel that reads it has run."""
+    d = t.cuda().contiguous()
+    _KEEP.append(d)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return d
 
 
 def rnd(shape, name, scale=1.0):
@@ -211,7 +221,7 @@ def test_fill_gumbel_statistics_and_keying(lib):
     B, nb, T, W = 2, 2, 500, 4
     n = nb * B * T * W
     a = torch.zeros(n, device="cuda")
-    b = torch.zeros(n, device="cuda")
+    b = torch.zeros(nb * 1 * T * W, device="cuda")
     L.check(lib.vb_fill_gumbel(L.ptr(a), B, nb, T, W, 99, 0, 3, 1, 2, L.stream_ptr()), "fill_gumbel")
     L.check(lib.vb_fill_gumbel(L.ptr(b), 1, nb, T, W, 99, 1, 3, 1, 2, L.stream_ptr()), "fill_gumbel")   # clip 1 alone
     sync()

@@ -58,6 +58,7 @@ class DiTEngine:
 
     def __init__(self, ctx: Context, cfg: DiTConfig, state_dict: Dict[str, Tensor], precision: str = "bf16"):
         assert precision in ("bf16", "split")
+        ctx = Context(ctx.device)        # a vb_ctx holds ONE loaded DiT: every engine owns its handle
         self.ctx, self.cfg, self.precision = ctx, cfg, precision
         self.np = 2 if precision == "split" else 1
         dev = ctx.device
@@ -205,6 +206,7 @@ class NetBuilder:
 
 class ConvNet:
     def __init__(self, ctx: Context, which: int, nb: NetBuilder, in_ch: int, out_ch: int, out_tmul: int):
+        ctx = Context(ctx.device)        # one program per (vb_ctx, slot): every net owns its handle
         self.ctx, self.which, self.nb = ctx, which, nb
         self.in_ch, self.out_ch, self.out_tmul = in_ch, out_ch, out_tmul
         ops = (L.NetOp * len(nb.ops))(*nb.ops)
