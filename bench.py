@@ -33,6 +33,26 @@ PEAK = {0: ("mfma", 2500.0, "bf16 MFMA GEMM (DiT projections + experts)"),
         2: ("mfma", 157.3, "fp32 MFMA implicit-GEMM conv1d (VAE + HiFi-GAN)")}
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """threads the CPU baseline may use: affinity mask, capped by the cgroup CPU quota (a container that
+    reports 256 CPUs but is throttled to a few would otherwise spin 256 OpenMP threads on them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,7 +63,9 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
     ap.add_argument("--scale", type=float, default=3.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-flow-steps", type=int, default=6)
+    ap.add_argument("--cpu-flow-steps", type=int, default=4)
+    ap.add_argument("--cpu-timeout", type=float, default=240.0)
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -74,7 +96,7 @@ def cpu_baseline(sd_d, sd_v, sd_h, hp, flow_steps_total, cpu_steps, scale):
     from oracle import ref_cpu
     from tests.helpers import clip_batch, exp_noise
     from versband_amd import model as vm
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     inp = clip_batch(1, T_LAT, L_CTX, clip0=0, seed=SEED)
     t0 = time.perf_counter()
@@ -108,8 +130,37 @@ def cpu_baseline(sd_d, sd_v, sd_h, hp, flow_steps_total, cpu_steps, scale):
                       f"full HiFi-GAN {t_voc:.2f}s (torch fp32 oracle, routed experts, conditioning hoisted)"}
 
 
+def cpu_baseline_subprocess(args):
+    """run the CPU leg in its own process with a hard time bound so the bench can never hang on it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--flow-steps", str(args.flow_steps),
+           "--cpu-flow-steps", str(args.cpu_flow_steps), "--scale", str(args.scale)]
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "mel-s/s", "cores": usable_cores(), "kind": "port", "sample": "failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "mel-s/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"timed out after {args.cpu_timeout:.0f}s"}
+
+
+def cpu_worker(args):
+    from versband_amd import synth
+    dcfg, vcfg, hcfg = synth.DiTConfig(), synth.VAEConfig(), synth.HifiGanConfig()
+    sds = [synth.make_state_dict(s, SEED + i) for i, s in
+           enumerate([synth.dit_shapes(dcfg), synth.vae_decoder_shapes(vcfg), synth.hifigan_shapes(hcfg)])]
+    print(json.dumps(cpu_baseline(sds[0], sds[1], sds[2], hcfg.as_hparams(), args.flow_steps, args.cpu_flow_steps, args.scale)))
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        return cpu_worker(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,6 +185,7 @@ def main():
     sds_cpu = sds
     if world > 1:
         sds = broadcast_state(sds, rank, world, device)
+    log("weights ready; packing")
     ctx = Context(device)
     eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision)
     vae = build_vae_decoder(ctx, sds[1])
@@ -160,6 +212,7 @@ def main():
             torch.cuda.synchronize()
 
     lib = L.load()
+    log("engines built; warmup")
 
     def read_prof(cls):
         ms, fl, n, nt = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
@@ -182,6 +235,7 @@ def main():
             dominant = max(breakdown, key=breakdown.get)
     assert torch.isfinite(wav).all()
     L.check(lib.vb_prof_enable(1 << dominant), "prof")
+    log(f"warmup done; class ms/pass = {breakdown}; timing {args.steps} step(s)")
 
     barrier()
     t0 = time.perf_counter()
@@ -194,6 +248,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    log(f"timed region: {elapsed:.3f}s")
     ms, fl, n, nt = read_prof(dominant)
     L.check(lib.vb_prof_enable(0), "prof")
 
@@ -224,8 +279,8 @@ def main():
                          "class_ms_per_step_warmup": {PEAK[c][2]: round(v, 3) for c, v in breakdown.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sds_cpu[0], sds_cpu[1], sds_cpu[2], hcfg.as_hparams(), args.flow_steps,
-                                               args.cpu_flow_steps, args.scale)
+            log("cpu baseline (subprocess, bounded)")
+            out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -104,6 +104,11 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: it must be the first libamdhip64 in the process, otherwise this
+    # library would bind /opt/rocm's copy and run against a second, device-less runtime instance
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
