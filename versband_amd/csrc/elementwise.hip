@@ -150,75 +150,6 @@ int launch_fill_f32(float* p, int64_t n, float v, hipStream_t st) {
     return VB_OK;
 }
 
-// ---------------------------------------------------------------------------
-// Row GEMV for the per-item conditioning vectors (t-embedder MLP, adaLN of all blocks in
-// one launch, high-level gates):  out[r][n] = bias[n] + sum_k W[n][k] * act(x[r][k] + x2[r%mod][k])
-// x rows may be gathered (x_row_idx: row r reads x + idx[r]*x_ld) - used for the
-// timestep table lookup.  16 rows x 64 outputs per block; act(x) staged in LDS once.
-// ---------------------------------------------------------------------------
-#define GV_R 16
-#define GV_N 64
-__global__ void __launch_bounds__(256) gemv_rows_kernel(const float* __restrict__ x, int x_ld, const int64_t* x_row_idx,
-                                                       const float* __restrict__ x2, int x2_ld, int x2_mod,
-                                                       const float* __restrict__ W, const float* __restrict__ bias, int R, int N,
-                                                       int K, int act_in, float* out, int out_ld) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];   // [GV_R][K]
-    const int r0 = blockIdx.y * GV_R;
-    const int nr = min(GV_R, R - r0);
-    for (int id = threadIdx.x; id < GV_R * K; id += 256) {
-        int r = id / K, k = id - r * K;
-        float v = 0.f;
-        if (r < nr) {
-            int64_t xr = x_row_idx ? x_row_idx[r0 + r] : (r0 + r);
-            v = x[xr * x_ld + k];
-            if (x2) v += x2[(int64_t)((r0 + r) % x2_mod) * x2_ld + k];
-            if (act_in == 1) v = v / (1.f + expf(-v));
-        }
-        xs[id] = v;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = 0; i < GV_N / 4; ++i) {
-        const int n = blockIdx.x * GV_N + wave * (GV_N / 4) + i;
-        if (n >= N) break;
-        float acc[GV_R];
-#pragma unroll
-        for (int r = 0; r < GV_R; ++r) acc[r] = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)n * K + k);
-#pragma unroll
-            for (int r = 0; r < GV_R; ++r) {
-                const float4 xv = *reinterpret_cast<const float4*>(xs + r * K + k);
-                acc[r] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < GV_R; ++r) {
-            float s = wave_sum(acc[r]);
-            if (lane == 0 && r < nr) out[(int64_t)(r0 + r) * out_ld + n] = s + (bias ? bias[n] : 0.f);
-        }
-    }
-}
-int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* W,
-                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
-    if (K % 4 || K > 2048) VB_FAIL(VB_E_INVALID, "gemv: K=%d must be %%4 and <= 2048", K);
-    dim3 grid(cdiv(N, GV_N), cdiv(R, GV_R));
-    size_t sh = (size_t)GV_R * K * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemv_rows_kernel, grid, dim3(256), sh, st, x, x_ld, idx, x2, x2_ld, x2_mod > 0 ? x2_mod : 1, W, bias, R, N, K,
-                       act_in, out, out_ld);
-    VB_CHECK_LAUNCH();
-    return VB_OK;
-}
-int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias, int R,
-                     int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
-    return launch_gemv_rows_idx(x, x_ld, nullptr, x2, x2_ld, x2_mod, W, bias, R, N, K, act_in, out, out_ld, st);
-}
-
 // mean over L rows: [B][L][D] -> [B][D]   (pooled caption, vocal2music_moe.py:410-412)
 __global__ void mean_rows_kernel(const float* __restrict__ x, int B, int L, int D, float* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,41 +226,6 @@ int launch_transpose_bct_btc(const float* in, int B, int C, int T_in, int T_out,
     return VB_OK;
 }
 
-// ---------------------------------------------------------------------------
-// FinalLayer (vocal2music_moe.py:287-291): LN(no affine, eps) -> modulate -> Linear(D->C) -> out[b][c][t]
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) final_layer_kernel(const float* __restrict__ h, const float* shift, const float* scale,
-                                                         int mod_ld, const float* __restrict__ W, const float* __restrict__ bias,
-                                                         int rows, int D, int T, int C, float eps, float* out) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* x = h + (int64_t)row * D;
-    const int b = row / T, t = row - b * T;
-    float s = 0.f;
-    for (int k = lane; k < D; k += 64) s += x[k];
-    const float mean = wave_sum(s) / (float)D;
-    float vs = 0.f;
-    for (int k = lane; k < D; k += 64) { float d = x[k] - mean; vs += d * d; }
-    const float r = rsqrtf(wave_sum(vs) / (float)D + eps);
-    for (int c = 0; c < C; ++c) {
-        float acc = 0.f;
-        for (int k = lane; k < D; k += 64) {
-            float y = (x[k] - mean) * r;
-            y = y * (1.f + scale[(int64_t)b * mod_ld + k]) + shift[(int64_t)b * mod_ld + k];
-            acc += y * W[(int64_t)c * D + k];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) out[((int64_t)b * C + c) * T + t] = acc + bias[c];
-    }
-}
-int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
-                       int rows, int D, int T, int C, float eps, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(final_layer_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, shift, scale, mod_ld, W, bias, rows, D, T, C, eps,
-                       out);
-    VB_CHECK_LAUNCH();
-    return VB_OK;
-}
 
 // ---------------------------------------------------------------------------
 // CFG + Euler:  x[b] += dt * (v_u + s*(v_c - v_u))     (cfm1_audio.py:160 + fixed-step Euler)

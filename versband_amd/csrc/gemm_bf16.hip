@@ -255,9 +255,127 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_kernel(const GemmDev p) {
     }
 }
 
+
+// ---- variant 2: tiles DMA'd straight into LDS (global_load_lds, 16 B / lane, no VGPR staging, no ds_write) ----------
+// The LDS image must be lane-linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane
+// SOURCE chunk instead: LDS slot (row, c') receives global chunk c = c' ^ ((row>>1)&7); the fragment reads use the
+// same involution.  Needs K % 64 == 0 (no zero fill on this path); out-of-range rows read a clamped valid row and
+// their results are never stored.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int EPI>
+__global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * BK * 2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    int g = 0, row0, rows_end;
+    {
+        int tmg = blockIdx.y;
+        if (p.group_off) {
+            bool found = false;
+            for (int gi = 0; gi < p.ngroups; ++gi) {
+                int lo = p.group_off[gi], hi = p.group_off[gi + 1];
+                int nt = (hi - lo + BM - 1) / BM;
+                if (tmg < nt) { g = gi; row0 = lo + tmg * BM; rows_end = hi; found = true; break; }
+                tmg -= nt;
+            }
+            if (!found) return;
+        } else {
+            g = blockIdx.z;
+            row0 = tmg * BM; rows_end = p.M;
+            if (row0 >= rows_end) return;
+        }
+    }
+    const int n0 = blockIdx.x * BN;
+    const int KT = p.K / BK;
+    const int total = KT * p.nseg;
+
+    // this lane's 4 A-pieces and 4 B-pieces of every K tile: segment s = wave*4+i covers tile rows 8s..8s+7
+    const bf16_t* asrc[4]; const bf16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = wave * 4 + i;
+        const int r = 8 * s + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int slot = row0 + r;
+        if (slot >= rows_end) slot = row0;
+        const int arow = p.a_rows ? p.a_rows[slot] : slot;
+        asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
+        int nrow = n0 + r;
+        if (nrow >= p.N) nrow = 0;
+        bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
+    }
+    auto issue = [&](int t, int buf) {
+        const int seg = t / KT;
+        const int k0 = (t - seg * KT) * BK;
+        const int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
+        const int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ao), (lds_ptr_t)(&lds[buf][0][s * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + bo), (lds_ptr_t)(&lds[buf][1][s * 1024]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < total; ++t) {
+        const int buf = t & 1;
+        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): this wave's pieces of tile t have landed
+        __syncthreads();                        // ... and everyone else's; everyone is done reading buf^1
+        if (t + 1 < total) issue(t + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bf[2];
+            const int c = ks * 2 + fk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(&lds[buf][0][lds_off(wr * 64 + i * 32 + frow, c)]);
+                bf[i] = *reinterpret_cast<const bf16x8*>(&lds[buf][1][lds_off(wc * 64 + i * 32 + frow, c)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int slot = row0 + wr * 64 + i * 32 + frow;
+        if (slot >= rows_end) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
+                if (n >= p.N) continue;
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                epilogue4<EPI>(p, g, slot, n, v);
+            }
+        }
+    }
+}
+
 template <int EPI>
 static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
+    if (d.K % BK == 0) hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {

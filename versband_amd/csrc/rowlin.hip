@@ -1,0 +1,121 @@
+// fp32 "few rows x wide weight" linears (gfx950): the per-item conditioning GEMVs (t-embedder MLP, the adaLN
+// modulations of ALL blocks + final layer in one launch, high-level gate logits) and the DiT FinalLayer.
+//
+// Layout of the work: a block owns 16 input rows (staged once in LDS, activation / LayerNorm+modulate applied
+// while staging) and a slab of outputs.  Inside a wave, lane = (row r = lane & 15, output slot o = lane >> 4):
+// each lane runs a private K-long dot product for ONE (row, output) pair - the 16 lanes of an output share the
+// weight address (one broadcast 16-B fetch), the 16 rows sit in distinct LDS banks (row pitch K+4 floats) - so
+// there is no cross-lane reduction at all (the v1 kernel spent its time in 96 shuffles per output).
+#include "kernels.h"
+
+#define RL_R 16
+
+template <int MODE>   // 0: out[r][n] = b[n] + W[n] . act(x[r] (+ x2[r % mod]))      1: FinalLayer, out[(b*C+n)*T + t]
+__global__ void __launch_bounds__(256) rowlin_kernel(const float* __restrict__ x, int x_ld, const int64_t* x_row_idx,
+                                                    const float* __restrict__ x2, int x2_ld, int x2_mod,
+                                                    const float* shift, const float* scale, int mod_ld, int T, float eps,
+                                                    const float* __restrict__ W, const float* __restrict__ bias, int R, int N, int K,
+                                                    int act_in, int n_per_block, float* out, int out_ld) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [RL_R][K + 4]
+    const int KP = K + 4;
+    const int r0 = blockIdx.y * RL_R;
+    const int nr = min(RL_R, R - r0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (MODE == 0) {
+        for (int id = threadIdx.x; id < RL_R * K; id += 256) {
+            int r = id / K, k = id - r * K;
+            float v = 0.f;
+            if (r < nr) {
+                int64_t xr = x_row_idx ? x_row_idx[r0 + r] : (int64_t)(r0 + r);
+                v = x[xr * x_ld + k];
+                if (x2) v += x2[(int64_t)((r0 + r) % x2_mod) * x2_ld + k];
+                if (act_in == 1) v = v / (1.f + expf(-v));
+            }
+            xs[r * KP + k] = v;
+        }
+    } else {
+        // LayerNorm (no affine) + modulate, one wave per row (4 rows per wave)
+        for (int r = wave; r < RL_R; r += 4) {
+            if (r < nr) {
+                const float* xr = x + (int64_t)(r0 + r) * x_ld;
+                float s = 0.f;
+                for (int k = lane; k < K; k += 64) s += xr[k];
+                const float mean = wave_sum(s) / (float)K;
+                float vs = 0.f;
+                for (int k = lane; k < K; k += 64) { float d = xr[k] - mean; vs += d * d; }
+                const float rs = rsqrtf(wave_sum(vs) / (float)K + eps);
+                const int b = (r0 + r) / T;
+                for (int k = lane; k < K; k += 64) {
+                    float y = (xr[k] - mean) * rs;
+                    xs[r * KP + k] = y * (1.f + scale[(int64_t)b * mod_ld + k]) + shift[(int64_t)b * mod_ld + k];
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) xs[r * KP + k] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int r = lane & 15, o = lane >> 4;
+    const float* xrow = xs + r * KP;
+    const int n_begin = blockIdx.x * n_per_block;
+    const int n_end = min(N, n_begin + n_per_block);
+    for (int nb = n_begin + wave * 4; nb < n_end; nb += 16) {
+        const int n = nb + o;
+        const bool ok = n < n_end;
+        const float* wrow = W + (int64_t)(ok ? n : n_begin) * K;
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < K; k += 8) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wrow + k);
+            const float4 w1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+            const float4 x0 = *reinterpret_cast<const float4*>(xrow + k);
+            const float4 x1 = *reinterpret_cast<const float4*>(xrow + k + 4);
+            a0 += w0.x * x0.x + w0.y * x0.y + w0.z * x0.z + w0.w * x0.w;
+            a1 += w1.x * x1.x + w1.y * x1.y + w1.z * x1.z + w1.w * x1.w;
+        }
+        if (ok && r < nr) {
+            const float v = a0 + a1 + (bias ? bias[n] : 0.f);
+            if constexpr (MODE == 0) {
+                out[(int64_t)(r0 + r) * out_ld + n] = v;
+            } else {
+                const int row = r0 + r, b = row / T, t = row - b * T;
+                out[((int64_t)b * N + n) * T + t] = v;
+            }
+        }
+    }
+}
+
+template <int MODE>
+static int launch_rowlin(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* shift,
+                         const float* scale, int mod_ld, int T, float eps, const float* W, const float* bias, int R, int N, int K,
+                         int act_in, float* out, int out_ld, hipStream_t st) {
+    if (K % 8 || K > 4096) VB_FAIL(VB_E_INVALID, "rowlin: K=%d must be %%8 and <= 4096", K);
+    // slab of outputs per block: enough blocks to fill the chip, at least 16 outputs (one pass of the 4 waves)
+    const int row_groups = cdiv(R, RL_R);
+    int npb = 64;
+    while (npb > 16 && (int64_t)cdiv(N, npb) * row_groups < 512) npb >>= 1;
+    dim3 grid(cdiv(N, npb), row_groups);
+    size_t sh = (size_t)RL_R * (K + 4) * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[MODE]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set[MODE] = true;
+    }
+    hipLaunchKernelGGL(rowlin_kernel<MODE>, grid, dim3(256), sh, st, x, x_ld, idx, x2, x2_ld, x2_mod > 0 ? x2_mod : 1, shift, scale, mod_ld,
+                       T > 0 ? T : 1, eps, W, bias, R, N, K, act_in, npb, out, out_ld);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* W,
+                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
+    return launch_rowlin<0>(x, x_ld, idx, x2, x2_ld, x2_mod, nullptr, nullptr, 0, 1, 0.f, W, bias, R, N, K, act_in, out, out_ld, st);
+}
+int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias, int R,
+                     int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
+    return launch_rowlin<0>(x, x_ld, nullptr, x2, x2_ld, x2_mod, nullptr, nullptr, 0, 1, 0.f, W, bias, R, N, K, act_in, out, out_ld, st);
+}
+// FinalLayer (vocal2music_moe.py:287-291): LN(no affine, eps) -> modulate -> Linear(D->C) -> out[b][c][t]
+int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                       int rows, int D, int T, int C, float eps, float* out, hipStream_t st) {
+    return launch_rowlin<1>(h, D, nullptr, nullptr, 0, 1, shift, scale, mod_ld, T, eps, W, bias, rows, C, D, 0, out, 0, st);
+}
