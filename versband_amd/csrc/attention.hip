@@ -29,7 +29,7 @@ struct AttnDev {
     const float* cross_w;
     bf16_t* out; int64_t out_plane; int out_np;
     int B, T, Tpad, L, Lpad, H, D;
-    int has_self, has_cross, kv_batch_mod;
+    int has_self, has_cross, kv_batch_mod, nq;
     float scale_log2e;
 };
 
@@ -41,8 +41,12 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5, ql = lane & 31;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware order: the q-tiles of one (batch, head) are consecutive blocks of the same XCD so its K/V stay in that L2
+    const int Lb = blockIdx.x, jx = Lb >> 3;
+    const int bh = (jx / p.nq) * 8 + (Lb & 7);
+    if (bh >= p.B * p.H) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = (jx % p.nq) * 128 + wave * 32;
     const int qrow = q0 + ql;
     const int qrow_c = qrow < p.T ? qrow : p.T - 1;
 
@@ -227,7 +231,8 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     d.has_self = a.has_self; d.has_cross = a.has_cross; d.kv_batch_mod = a.kv_batch_mod;
     d.scale_log2e = a.scale * 1.4426950408889634f;
     ProfScope prof(1, 4.0 * a.B * a.H * a.T * a.hd * ((a.has_self ? a.T : 0) + (a.has_cross ? a.L : 0)), st);
-    dim3 grid(cdiv(a.T, 128), a.B * a.H);
+    d.nq = cdiv(a.T, 128);
+    dim3 grid(d.nq * ((a.B * a.H + 7) / 8 * 8));
     if (a.q.np == 2) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, d);
     VB_CHECK_LAUNCH();

@@ -29,7 +29,7 @@ struct GemmDev {
     bf16_t* out; int64_t out_plane; int out_np; int ldc;
     float* out32; int ldc32;
     const float* gate; int gate_ld; int T;
-    const int* rows_out; const float* row_scale; const float* y32_in;
+    const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
 };
@@ -142,9 +142,14 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_kernel(const GemmDev p) {
     const int wr = wave >> 1, wc = wave & 1;
 
     // ---- which (group, m-tile) is this block -------------------------------------
-    int g = 0, row0, rows_end;
+    int g = 0, row0, rows_end, tile_n;
     {
-        int tmg = blockIdx.y;
+        // XCD-aware tile order: block L runs on XCD L%8 (8 private L2s).  All N-tiles of one M-tile are
+        // consecutive blocks of the SAME XCD, so an A tile is fetched into one L2 once instead of once per N-tile.
+        const int L = blockIdx.x, nN = p.n_tiles;
+        const int jx = L >> 3;
+        tile_n = jx % nN;
+        int tmg = (jx / nN) * 8 + (L & 7);
         if (p.group_off) {
             bool found = false;
             for (int gi = 0; gi < p.ngroups; ++gi) {
@@ -160,7 +165,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_kernel(const GemmDev p) {
             if (row0 >= rows_end) return;
         }
     }
-    const int n0 = blockIdx.x * BN;
+    const int n0 = tile_n * BN;
     const int K = p.K;
     const int KT = (K + BK - 1) / BK;
     const int total = KT * p.nseg;
@@ -273,9 +278,14 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
 
-    int g = 0, row0, rows_end;
+    int g = 0, row0, rows_end, tile_n;
     {
-        int tmg = blockIdx.y;
+        // XCD-aware tile order: block L runs on XCD L%8 (8 private L2s).  All N-tiles of one M-tile are
+        // consecutive blocks of the SAME XCD, so an A tile is fetched into one L2 once instead of once per N-tile.
+        const int L = blockIdx.x, nN = p.n_tiles;
+        const int jx = L >> 3;
+        tile_n = jx % nN;
+        int tmg = (jx / nN) * 8 + (L & 7);
         if (p.group_off) {
             bool found = false;
             for (int gi = 0; gi < p.ngroups; ++gi) {
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
             if (row0 >= rows_end) return;
         }
     }
-    const int n0 = blockIdx.x * BN;
+    const int n0 = tile_n * BN;
     const int KT = p.K / BK;
     const int total = KT * p.nseg;
 
@@ -395,7 +405,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
     ProfScope prof(0, 2.0 * a.M * a.N * a.K * ((a.group_off || a.ngroups <= 1) ? 1 : a.ngroups), st);
     int mt = a.group_off ? (cdiv(a.M, BM) + a.ngroups) : cdiv(a.M, BM);
-    dim3 grid(cdiv(a.N, BN), mt, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
+    d.n_tiles = cdiv(a.N, BN);
+    dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
     switch (a.epi) {
         case EPI_PLANES: launch_t<EPI_PLANES>(d, grid, st); break;
         case EPI_F32: launch_t<EPI_F32>(d, grid, st); break;
