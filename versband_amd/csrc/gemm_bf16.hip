@@ -14,6 +14,8 @@
 //    (A_hi,B_lo) - three bf16 passes give fp32-class products.
 //  * Grouped problems (Band-MoE experts): the grid's y index walks the m-tiles of all
 //    groups; group row ranges come from a device array written by the bucket kernel.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define BM 128
@@ -261,17 +263,37 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_kernel(const GemmDev p) {
 }
 
 
-// ---- variant 2: tiles DMA'd straight into LDS (global_load_lds, 16 B / lane, no VGPR staging, no ds_write) ----------
+// ---- variant 2: tiles DMA'd straight into an LDS ring (global_load_lds, 16 B / lane, no VGPR staging, no ds_write) ----
 // The LDS image must be lane-linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane
-// SOURCE chunk instead: LDS slot (row, c') receives global chunk c = c' ^ ((row>>1)&7); the fragment reads use the
-// same involution.  Needs K % 64 == 0 (no zero fill on this path); out-of-range rows read a clamped valid row and
-// their results are never stored.
+// SOURCE chunk instead: LDS slot (row, c') receives global chunk c = c' ^ swz(row); the fragment reads use the same
+// involution.  NST stages: tiles t+1 .. t+NST-1 are in flight while tile t is multiplied; the wait is a COUNTED
+// s_waitcnt vmcnt((NST-2)*loads_per_tile) + a raw s_barrier, so the DMA queue is never drained inside the loop.
+// Needs K % BKT == 0 (no zero fill on this path); out-of-range rows read a clamped valid row and are never stored.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int EPI>
+template <int BKT> __device__ __forceinline__ int lds_off_t(int row, int c) {
+    if constexpr (BKT == 64) return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+    else return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) __builtin_amdgcn_s_waitcnt(0x0f70);
+    else if constexpr (N == 4) __builtin_amdgcn_s_waitcnt(0x0f74);
+    else if constexpr (N == 8) __builtin_amdgcn_s_waitcnt(0x0f78);
+    else if constexpr (N == 12) __builtin_amdgcn_s_waitcnt(0x0f7c);
+    else if constexpr (N == 16) __builtin_amdgcn_s_waitcnt(0x4f70);
+    else if constexpr (N == 24) __builtin_amdgcn_s_waitcnt(0x4f78);
+    else static_assert(N == 0, "unsupported vmcnt");
+}
+
+template <int EPI, int BKT, int NST>
 __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][BM * BK * 2];
+    constexpr int CH = BKT / 8;              // 16-B chunks per tile row
+    constexpr int RS = 64 / CH;              // tile rows covered by one wave-wide DMA (1 KB)
+    constexpr int SPW = CH / 2;              // DMA pieces per wave per operand per tile
+    constexpr int LPT = 2 * SPW;             // loads per wave per tile
+    constexpr int OPB = BM * BKT * 2;        // bytes of one operand tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * OPB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -280,8 +302,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
 
     int g = 0, row0, rows_end, tile_n;
     {
-        // XCD-aware tile order: block L runs on XCD L%8 (8 private L2s).  All N-tiles of one M-tile are
-        // consecutive blocks of the SAME XCD, so an A tile is fetched into one L2 once instead of once per N-tile.
         const int L = blockIdx.x, nN = p.n_tiles;
         const int jx = L >> 3;
         tile_n = jx % nN;
@@ -302,16 +322,16 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         }
     }
     const int n0 = tile_n * BN;
-    const int KT = p.K / BK;
+    const int KT = p.K / BKT;
     const int total = KT * p.nseg;
 
-    // this lane's 4 A-pieces and 4 B-pieces of every K tile: segment s = wave*4+i covers tile rows 8s..8s+7
-    const bf16_t* asrc[4]; const bf16_t* bsrc[4];
+    const bf16_t* asrc[SPW]; const bf16_t* bsrc[SPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int s = wave * 4 + i;
-        const int r = 8 * s + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+    for (int i = 0; i < SPW; ++i) {
+        const int s = wave * SPW + i;
+        const int r = RS * s + lane / CH;
+        const int cs = lane % CH;
+        const int c = (BKT == 64) ? (cs ^ ((r >> 1) & 7)) : (cs ^ ((r >> 2) & 3));
         int slot = row0 + r;
         if (slot >= rows_end) slot = row0;
         const int arow = p.a_rows ? p.a_rows[slot] : slot;
@@ -320,16 +340,17 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         if (nrow >= p.N) nrow = 0;
         bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
     }
-    auto issue = [&](int t, int buf) {
+    auto issue = [&](int t) {
+        const int st = t % NST;
         const int seg = t / KT;
-        const int k0 = (t - seg * KT) * BK;
+        const int k0 = (t - seg * KT) * BKT;
         const int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
         const int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ao), (lds_ptr_t)(&lds[buf][0][s * 1024]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + bo), (lds_ptr_t)(&lds[buf][1][s * 1024]), 16, 0, 0);
+        for (int i = 0; i < SPW; ++i) {
+            const int s = wave * SPW + i;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ao), (lds_ptr_t)(&lds[(st * 2 + 0) * OPB + s * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + bo), (lds_ptr_t)(&lds[(st * 2 + 1) * OPB + s * 1024]), 16, 0, 0);
         }
     };
 
@@ -341,21 +362,29 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < total) issue(t);
     const int frow = lane & 31, fk = lane >> 5;
     for (int t = 0; t < total; ++t) {
-        const int buf = t & 1;
-        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): this wave's pieces of tile t have landed
-        __syncthreads();                        // ... and everyone else's; everyone is done reading buf^1
-        if (t + 1 < total) issue(t + 1, buf ^ 1);
+        const int st = t % NST;
+        // tiles t+1 .. min(total-1, t+NST-2) may stay in flight
+        const int ahead = min(total - 1, t + NST - 2) - t;
+        if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
+        else if (NST >= 3 && ahead >= 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();           // tile t landed everywhere; everyone finished reading stage (t-1)%NST
+        if (t + NST - 1 < total) issue(t + NST - 1);
+        const unsigned char* As = &lds[(st * 2 + 0) * OPB];
+        const unsigned char* Bs = &lds[(st * 2 + 1) * OPB];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < BKT / 16; ++ks) {
             bf16x8 af[2], bf[2];
             const int c = ks * 2 + fk;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(&lds[buf][0][lds_off(wr * 64 + i * 32 + frow, c)]);
-                bf[i] = *reinterpret_cast<const bf16x8*>(&lds[buf][1][lds_off(wc * 64 + i * 32 + frow, c)]);
+                af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
+                bf[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -384,7 +413,14 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
 
 template <int EPI>
 static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
-    if (d.K % BK == 0) hipLaunchKernelGGL(gemm_bf16_glds_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
+    // VB_GEMM_VARIANT (tuning knob): 0 register-staged, 1 DMA BK=64 x2 stages, 2 DMA BK=32 x4 stages, 3 DMA BK=32 x3 stages,
+    // 4 DMA BK=64 x3 stages.  Default 2.
+    const char* ev = getenv("VB_GEMM_VARIANT");
+    const int variant = ev ? atoi(ev) : 2;
+    if (variant == 1 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2>), grid, dim3(NTHREADS), 0, st, d);
+    else if (variant == 2 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);
+    else if (variant == 3 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d);
+    else if (variant == 4 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d);
     else hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
 }
 
