@@ -161,6 +161,7 @@ typedef struct {
     const float* w; const float* bias; const float* gn_gamma; const float* gn_beta;
     int Ci, Co, ksize, dil, pad, upsample2, in_act, out_act, out_transposed, tr_stride, tr_pad, tr_k, gn_groups;
     float in_slope, out_slope, alpha, beta, acc_scale;
+    const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
 } vb_net_op;
 
 enum { VB_NET_VAE = 0, VB_NET_VOCODER = 1 };
@@ -190,10 +191,11 @@ int vb_grouped_swiglu(const void* u, const int32_t* perm, const int32_t* group_o
 /* fused self (+cross) attention, head_dim 96 (Attention.forward, flag_large_dit_moe.py:381-402) */
 int vb_attention(const void* q, const void* k, const void* vt, const void* ky, const void* vyt, const float* cross_w, int B, int T,
                  int Tpad, int L, int Lpad, int H, int hd, int np, void* out, void* stream);
-/* fp32 Conv1d / ConvTranspose1d on [B][C][T] (weights packed [phase][tap][Ci][Co]) */
+/* fp32 Conv1d / ConvTranspose1d on [B][C][T] (weights packed [phase][tap][Ci][Co]); w_x3 != NULL runs the
+ * split-bf16 (bf16x3) MFMA kernel on weights packed [2][phase][tap][Co][ci_pad] instead of the exact-f32 MFMA kernel */
 int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil, int pad,
                   int tr_stride, int tr_pad, int tr_k, int T_out, int in_act, float in_slope, const float* res, float* out,
-                  void* stream);
+                  const void* w_x3, int ci_pad, void* stream);
 /* counter-based Gumbel draws: out[rows][w], rows = n_branch*B*T */
 int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
                    void* stream);

@@ -38,8 +38,8 @@ def test_struct_layouts_match_header_field_order():
     assert re.findall(r"\*\s*([a-z0-9_]+)\s*;", top) == L.TOP_FIELDS
     op = re.search(r"typedef struct \{\s*int kind;(.*?)\} vb_net_op;", src, flags=re.S).group(1)
     op = re.sub(r"/\*.*?\*/", "", op, flags=re.S)
-    fields = ["kind"] + [n.strip().lstrip("*") for decl in re.findall(r"(?:int|const float\*|float)\s+([^;]+);", op)
-                         for n in decl.replace("const float*", "").split(",")]
+    fields = ["kind"] + [n.strip().lstrip("*") for decl in re.findall(r"(?:int|const float\*|const void\*|float)\s+([^;]+);", op)
+                         for n in decl.replace("const float*", "").replace("const void*", "").split(",")]
     assert fields == [f[0] for f in L.NetOp._fields_], fields
 
 

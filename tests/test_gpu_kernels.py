@@ -75,33 +75,39 @@ CONV_CASES = [  # B, Ci, T, Co, k, dil, in_act, res
 
 
 @pytest.mark.parametrize("B,Ci,T,Co,k,dil,act,res", CONV_CASES)
-def test_conv1d_f32(lib, B, Ci, T, Co, k, dil, act, res):
+@pytest.mark.parametrize("split", [False, True])
+def test_conv1d_f32(lib, B, Ci, T, Co, k, dil, act, res, split):
     x, w, b = rnd((B, Ci, T), "cx"), rnd((Co, Ci, k), "cw", 1.0 / (Ci * k) ** 0.5), rnd((Co,), "cb")
     r = rnd((B, Co, T), "cr") if res else None
     pad = (k - 1) * dil // 2
     out = torch.full((B, Co, T), float("nan"), device="cuda")
+    wx3, cip = pack.pack_conv_x3(pack.pack_conv(w))
     L.check(lib.vb_conv1d_f32(L.ptr(dev(x)), L.ptr(dev(pack.pack_conv(w))), L.ptr(dev(b)), B, Ci, T, Co, k, dil, pad, 1, 0, 0, T,
-                              act, 0.1, L.ptr(dev(r)) if res else None, L.ptr(out), L.stream_ptr()), "conv")
+                              act, 0.1, L.ptr(dev(r)) if res else None, L.ptr(out), L.ptr(dev(wx3)) if split else None, cip,
+                              L.stream_ptr()), "conv")
     sync()
     xin = F.leaky_relu(x.double(), 0.1) if act else x.double()
     ref = F.conv1d(xin, w.double(), b.double(), dilation=dil, padding=pad)
     if res:
         ref = ref + r.double()
-    assert rel_l2(out, ref) < 2e-6, describe("conv1d", out, ref)   # exact-fp32 MFMA: fp32 roundoff only
+    # exact-f32 MFMA: fp32 roundoff only; split-bf16: 2^-17 operand error
+    assert rel_l2(out, ref) < (2e-5 if split else 2e-6), describe("conv1d", out, ref)
 
 
 @pytest.mark.parametrize("B,Ci,T,Co,k,u", [(2, 512, 24, 256, 16, 8), (1, 256, 33, 128, 15, 5), (1, 128, 20, 64, 11, 5),
                                           (2, 64, 50, 32, 4, 2), (1, 128, 19, 64, 8, 4)])
-def test_conv_transpose1d_f32(lib, B, Ci, T, Co, k, u):
+@pytest.mark.parametrize("split", [False, True])
+def test_conv_transpose1d_f32(lib, B, Ci, T, Co, k, u, split):
     x, w, b = rnd((B, Ci, T), "tx"), rnd((Ci, Co, k), "tw", (u / (Ci * k)) ** 0.5), rnd((Co,), "tb")
     p = (k - u) // 2
     ref = F.conv_transpose1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), stride=u, padding=p)
     T_out = ref.shape[-1]
     out = torch.full((B, Co, T_out), float("nan"), device="cuda")
+    wx3, cip = pack.pack_conv_x3(pack.pack_conv_transpose(w, u))
     L.check(lib.vb_conv1d_f32(L.ptr(dev(x)), L.ptr(dev(pack.pack_conv_transpose(w, u))), L.ptr(dev(b)), B, Ci, T, Co, 0, 1, 0, u, p,
-                              k, T_out, 1, 0.1, None, L.ptr(out), L.stream_ptr()), "convT")
+                              k, T_out, 1, 0.1, None, L.ptr(out), L.ptr(dev(wx3)) if split else None, cip, L.stream_ptr()), "convT")
     sync()
-    assert rel_l2(out, ref) < 2e-6, describe("conv_transpose1d", out, ref)
+    assert rel_l2(out, ref) < (2e-5 if split else 2e-6), describe("conv_transpose1d", out, ref)
 
 
 # ---------------------------------------------------------------- attention ------

@@ -52,7 +52,8 @@ class NetOp(C.Structure):
                 + [(n, c_void_p) for n in ("w", "bias", "gn_gamma", "gn_beta")]
                 + [(n, c_int) for n in ("Ci", "Co", "ksize", "dil", "pad", "upsample2", "in_act", "out_act", "out_transposed",
                                         "tr_stride", "tr_pad", "tr_k", "gn_groups")]
-                + [(n, c_float) for n in ("in_slope", "out_slope", "alpha", "beta", "acc_scale")])
+                + [(n, c_float) for n in ("in_slope", "out_slope", "alpha", "beta", "acc_scale")]
+                + [("w_x3", c_void_p), ("ci_pad", c_int)])
 
 
 OP_CONV, OP_GN_STATS, OP_SOFTMAX_T = 0, 1, 2
@@ -87,7 +88,7 @@ PROTOTYPES = {
     "vb_grouped_swiglu": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P, P]),
     "vb_attention": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "vb_conv1d_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                              c_float, P, P, P]),
+                              c_float, P, P, P, c_int, P]),
     "vb_fill_gumbel": (c_int, [P, c_int, c_int, c_int, c_int, c_u64, c_i64, c_int, c_int, c_int, P]),
     "vb_cast_planes": (c_int, [P, c_i64, P, c_int, P]),
 }

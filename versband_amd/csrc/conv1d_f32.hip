@@ -32,7 +32,66 @@ struct ConvDev {
     int out_act; float out_slope;
     int out_transposed; const float* add; int64_t add_bstride; int add_bmod;
     int phases, tr_pad;      // phases == 1: ordinary convolution
+    const bf16_t* wp; int64_t wp_plane; int Ci_pad;   // split-bf16 weights [2 planes][phase][tap][Co][Ci_pad]
 };
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
+                                              int out_stride, int out_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    // ---- epilogue: lane owns output position n, 4 consecutive co per accumulator quad
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + (wn * TN + jn) * 32 + l31;
+        if (n >= n_count) continue;
+        const int t = n * out_stride + out_off;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int cob = co0 + (wm * TM + i) * 32 + 8 * rg + 4 * g;
+                if (cob >= p.Co) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int co = cob + e;
+                    float val = acc[i][jn][rg * 4 + e] * p.acc_scale;
+                    if (co < p.Co) {
+                        if (p.bias) val += p.bias[co];
+                    }
+                    v[e] = val;
+                }
+                if (p.out_transposed) {
+                    // out[b][t][co..co+3]   (Co % 4 == 0 enforced at launch)
+                    float4* dst = reinterpret_cast<float4*>(p.out + (int64_t)b * p.out_bstride + (int64_t)t * p.Co + cob);
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.add) {
+                        const int ab = p.add_bmod > 0 ? (b % p.add_bmod) : b;
+                        const float4 ad = *reinterpret_cast<const float4*>(p.add + (int64_t)ab * p.add_bstride + (int64_t)t * p.Co + cob);
+                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+                    }
+                    *dst = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int co = cob + e;
+                        if (co >= p.Co) continue;
+                        float val = v[e];
+                        const int64_t oi = (int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t;
+                        if (p.res) val += p.res[(int64_t)b * p.res_bstride + (int64_t)co * p.T_out + t];
+                        if (p.out_act == ACT_LRELU) val = val > 0.f ? val : val * p.out_slope;
+                        else if (p.out_act == ACT_TANH) val = tanhf(val);
+                        val *= p.alpha;
+                        if (p.beta != 0.f) val += p.beta * p.out[oi];
+                        p.out[oi] = val;
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv1d_f32_kernel(const ConvDev p) {
@@ -152,62 +211,185 @@ __global__ void __launch_bounds__(256) conv1d_f32_kernel(const ConvDev p) {
         }
     }
 
-    // ---- epilogue: lane owns output position n, 4 consecutive co per accumulator quad
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int n = n0 + (wn * TN + jn) * 32 + l31;
-        if (n >= n_count) continue;
-        const int t = n * out_stride + out_off;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int cob = co0 + (wm * TM + i) * 32 + 8 * rg + 4 * g;
-                if (cob >= p.Co) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int co = cob + e;
-                    float val = acc[i][jn][rg * 4 + e] * p.acc_scale;
-                    if (co < p.Co) {
-                        if (p.bias) val += p.bias[co];
-                    }
-                    v[e] = val;
-                }
-                if (p.out_transposed) {
-                    // out[b][t][co..co+3]   (Co % 4 == 0 enforced at launch)
-                    float4* dst = reinterpret_cast<float4*>(p.out + (int64_t)b * p.out_bstride + (int64_t)t * p.Co + cob);
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (p.add) {
-                        const int ab = p.add_bmod > 0 ? (b % p.add_bmod) : b;
-                        const float4 ad = *reinterpret_cast<const float4*>(p.add + (int64_t)ab * p.add_bstride + (int64_t)t * p.Co + cob);
-                        o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
-                    }
-                    *dst = o;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int co = cob + e;
-                        if (co >= p.Co) continue;
-                        float val = v[e];
-                        const int64_t oi = (int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t;
-                        if (p.res) val += p.res[(int64_t)b * p.res_bstride + (int64_t)co * p.T_out + t];
-                        if (p.out_act == ACT_LRELU) val = val > 0.f ? val : val * p.out_slope;
-                        else if (p.out_act == ACT_TANH) val = tanhf(val);
-                        val *= p.alpha;
-                        if (p.beta != 0.f) val += p.beta * p.out[oi];
-                        p.out[oi] = val;
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
 }
 
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg(const ConvDev& d, int n_count, int B, hipStream_t st) {
     dim3 grid(cdiv(n_count, WN * TN * 32), cdiv(d.Co, WM * TM * 32), B * d.phases);
     hipLaunchKernelGGL((conv1d_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, st, d);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") variant: same implicit GEMM, same fused staging and epilogue, but every fp32 operand is
+// split on the fly into a bf16 hi/lo pair and each product runs as hi*hi + lo*hi + hi*lo on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Operand error 2^-17 (fp32-class results, ~3e-5 max relative vs
+// the exact-f32 kernel) at 3 bf16 MFMAs per 16-deep k-step: 5.3x the f32-MFMA rate of gfx950 (157 TF vs 2.5 PF/3).
+// The activation window is transposed while staging: LDS holds xT[plane][t][ci] (ci contiguous, pitch 80 B so the
+// 16-B fragment reads of 16 consecutive t hit 16 distinct slots); weights are pre-packed [plane][tap][co][ci].
+// ---------------------------------------------------------------------------------------------------------
+#define CK3 32
+#define CKP3 40      // bf16 elements per LDS row (32 + 8 pad)
+
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
+    constexpr int CO_TILE = WM * TM * 32;
+    constexpr int T_TILE = WN * TN * 32;
+    constexpr int XW = T_TILE + XHALO;
+    __shared__ __attribute__((aligned(16))) bf16_t xT[2][XW * CKP3];
+    __shared__ __attribute__((aligned(16))) bf16_t wl[2][2][CO_TILE * CKP3];     // [buf][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    const int z = blockIdx.z;
+    const int b = z / p.phases, ph = z - b * p.phases;
+    const int n0 = blockIdx.x * T_TILE;
+    const int co0 = blockIdx.y * CO_TILE;
+
+    int in_off, out_off, out_stride, n_count;
+    if (p.phases == 1) {
+        in_off = -p.pad; out_off = 0; out_stride = 1; n_count = p.T_out;
+    } else {
+        const int u = p.phases;
+        const int d = p.tr_pad - ph;
+        const int q0 = d > 0 ? (d + u - 1) / u : 0;
+        in_off = q0 - (p.ntaps - 1);
+        out_off = q0 * u + ph - p.tr_pad;
+        out_stride = u;
+        n_count = (p.T_out - out_off + u - 1) / u;
+    }
+    if (n0 >= n_count) return;
+
+    const int halo = (p.ntaps - 1) * p.dil;
+    const int xw_used = T_TILE + halo;
+    const int T_eff = p.upsample2 ? 2 * p.T_in : p.T_in;
+    const int xb = p.x_bmod > 0 ? (b % p.x_bmod) : b;
+    const float* xbase = p.x + (int64_t)xb * p.x_bstride;
+    const bf16_t* wbase = p.wp + (int64_t)ph * p.ntaps * p.Co * p.Ci_pad;
+    const int cpg = p.gn_groups > 0 ? (p.Ci / p.gn_groups) : 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // weight tile of one (tap, chunk): CO_TILE rows x 32 ci x 2 planes = CO_TILE*8 pieces of 16 B
+    constexpr int WPT = CO_TILE * 8 / 256;
+    uint4 wreg[WPT];
+    auto wload = [&](int c0, int j) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int id = tid + i * 256;
+            const int pl = id / (CO_TILE * 4), rem = id - pl * (CO_TILE * 4);
+            const int co = rem >> 2, pc = rem & 3;
+            const int cog = co0 + co;
+            wreg[i] = (cog < p.Co) ? *reinterpret_cast<const uint4*>(wbase + pl * p.wp_plane + ((int64_t)j * p.Co + cog) * p.Ci_pad + c0 + pc * 8)
+                                   : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int id = tid + i * 256;
+            const int pl = id / (CO_TILE * 4), rem = id - pl * (CO_TILE * 4);
+            const int co = rem >> 2, pc = rem & 3;
+            *reinterpret_cast<uint4*>(&wl[buf][pl][co * CKP3 + pc * 8]) = wreg[i];
+        }
+    };
+
+    const int nchunks = (p.Ci + CK3 - 1) / CK3;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK3;
+        // ---- stage the activated window, split to bf16 hi/lo, transposed to [t][ci]; a wave owns ci pairs
+        for (int cp = wave; cp < CK3 / 2; cp += 4) {
+            const int ci0 = c0 + 2 * cp;
+            float gm[2] = {0.f, 0.f}, gr[2] = {1.f, 1.f}, gg[2] = {1.f, 1.f}, gb[2] = {0.f, 0.f};
+            bool cok[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                cok[e] = (ci0 + e) < p.Ci;
+                if (cok[e] && (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN)) {
+                    const int grp = (ci0 + e) / cpg;
+                    gm[e] = p.gn_mean[b * p.gn_groups + grp]; gr[e] = p.gn_rstd[b * p.gn_groups + grp];
+                    gg[e] = p.gn_gamma[ci0 + e]; gb[e] = p.gn_beta[ci0 + e];
+                }
+            }
+            const float* xrow0 = xbase + (int64_t)(cok[0] ? ci0 : 0) * p.T_in;
+            const float* xrow1 = xbase + (int64_t)(cok[1] ? ci0 + 1 : 0) * p.T_in;
+            for (int wpos = lane; wpos < xw_used; wpos += 64) {
+                const int idx = n0 + in_off + wpos;
+                float v[2] = {0.f, 0.f};
+                if (idx >= 0 && idx < T_eff) {
+                    const int si = p.upsample2 ? (idx >> 1) : idx;
+                    if (cok[0]) v[0] = xrow0[si];
+                    if (cok[1]) v[1] = xrow1[si];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (!cok[e]) continue;
+                        if (p.in_act == ACT_LRELU) {
+                            v[e] = v[e] > 0.f ? v[e] : v[e] * p.in_slope;
+                        } else if (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN) {
+                            v[e] = (v[e] - gm[e]) * gr[e] * gg[e] + gb[e];
+                            if (p.in_act == ACT_GN_SWISH) v[e] = v[e] / (1.f + __expf(-v[e]));
+                        }
+                    }
+                }
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 hi, lo;
+                hi[0] = f2bf(v[0]); hi[1] = f2bf(v[1]);
+                lo[0] = f2bf(v[0] - bf2f(hi[0])); lo[1] = f2bf(v[1] - bf2f(hi[1]));
+                *reinterpret_cast<bf16x2*>(&xT[0][wpos * CKP3 + 2 * cp]) = hi;
+                *reinterpret_cast<bf16x2*>(&xT[1][wpos * CKP3 + 2 * cp]) = lo;
+            }
+        }
+        wload(c0, 0);
+        wstore(0);
+        __syncthreads();
+        for (int j = 0; j < p.ntaps; ++j) {
+            const int buf = j & 1;
+            if (j + 1 < p.ntaps) wload(c0, j + 1);
+            const int xoff = j * p.dil;
+#pragma unroll
+            for (int ks = 0; ks < CK3 / 16; ++ks) {
+                const int kofs = ks * 16 + g * 8;
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int o = ((wm * TM + i) * 32 + l31) * CKP3 + kofs;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&wl[buf][0][o]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&wl[buf][1][o]);
+                }
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    const int o = ((wn * TN + jn) * 32 + l31 + xoff) * CKP3 + kofs;
+                    bh[jn] = *reinterpret_cast<const bf16x8*>(&xT[0][o]);
+                    bl[jn] = *reinterpret_cast<const bf16x8*>(&xT[1][o]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+                    }
+            }
+            if (j + 1 < p.ntaps) wstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg_x3(const ConvDev& d, int n_count, int B, hipStream_t st) {
+    dim3 grid(cdiv(n_count, WN * TN * 32), cdiv(d.Co, WM * TM * 32), B * d.phases);
+    hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, st, d);
 }
 
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
@@ -219,6 +401,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     d.out = a.out; d.out_bstride = a.out_bstride; d.T_out = a.T_out; d.res = a.res; d.res_bstride = a.res_bstride;
     d.alpha = a.alpha; d.beta = a.beta; d.acc_scale = a.acc_scale; d.out_act = a.out_act; d.out_slope = a.out_slope;
     d.out_transposed = a.out_transposed; d.add = a.add; d.add_bstride = a.add_bstride; d.add_bmod = a.add_bmod;
+    d.wp = a.wp; d.wp_plane = a.wp_plane; d.Ci_pad = a.Ci_pad;
     int n_count;
     if (a.tr_stride > 1) {
         d.phases = a.tr_stride; d.tr_pad = a.tr_pad; d.ntaps = (a.tr_k + a.tr_stride - 1) / a.tr_stride; d.dil = 1;
@@ -231,7 +414,12 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if (a.out_transposed && (a.Co % 4)) VB_FAIL(VB_E_INVALID, "conv1d: transposed output needs Co%%4==0");
     if ((a.in_act == ACT_GN_SWISH || a.in_act == ACT_GN) && (a.Ci % a.gn_groups)) VB_FAIL(VB_E_INVALID, "conv1d: Ci %% groups");
     ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * (a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize), st);
-    if (a.Co > 64) launch_cfg<2, 2, 2, 2>(d, n_count, a.B, st);
+    if (a.wp && !a.w_bstride) {
+        if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
+        if (a.Co > 64) launch_cfg_x3<2, 2, 2, 2>(d, n_count, a.B, st);
+        else if (a.Co > 32) launch_cfg_x3<2, 2, 1, 2>(d, n_count, a.B, st);
+        else launch_cfg_x3<1, 4, 1, 2>(d, n_count, a.B, st);
+    } else if (a.Co > 64) launch_cfg<2, 2, 2, 2>(d, n_count, a.B, st);
     else if (a.Co > 32) launch_cfg<2, 2, 1, 2>(d, n_count, a.B, st);
     else launch_cfg<1, 4, 1, 2>(d, n_count, a.B, st);
     VB_CHECK_LAUNCH();

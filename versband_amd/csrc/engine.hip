@@ -438,6 +438,11 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
             if (o.res != -1) { a.res = ptr(o.res); a.res_bstride = bstride(o.res); }
             a.alpha = o.alpha; a.beta = o.beta; a.acc_scale = o.acc_scale; a.out_act = o.out_act; a.out_slope = o.out_slope;
             a.out_transposed = o.out_transposed; a.B = B; a.tr_stride = o.tr_stride; a.tr_pad = o.tr_pad; a.tr_k = o.tr_k;
+            if (o.w_x3 && o.w_buf == -1) {
+                const int phases = o.tr_stride > 1 ? o.tr_stride : 1;
+                const int ntaps = o.tr_stride > 1 ? (o.tr_k + o.tr_stride - 1) / o.tr_stride : o.ksize;
+                a.wp = (const bf16_t*)o.w_x3; a.Ci_pad = o.ci_pad; a.wp_plane = (int64_t)phases * ntaps * a.Co * o.ci_pad;
+            }
             VB_TRY(launch_conv1d(a, st));
         } else {
             VB_FAIL(VB_E_INVALID, "net op %zu: bad kind %d", oi, o.kind);
@@ -628,8 +633,13 @@ int vb_attention(const void* q, const void* k, const void* vt, const void* ky, c
 }
 int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil, int pad,
                   int tr_stride, int tr_pad, int tr_k, int T_out, int in_act, float in_slope, const float* res, float* out,
-                  void* stream) {
+                  const void* w_x3, int ci_pad, void* stream) {
     ConvArgs a;
+    if (w_x3) {
+        const int phases = tr_stride > 1 ? tr_stride : 1;
+        const int ntaps = tr_stride > 1 ? (tr_k + tr_stride - 1) / tr_stride : ksize;
+        a.wp = (const bf16_t*)w_x3; a.Ci_pad = ci_pad; a.wp_plane = (int64_t)phases * ntaps * Co * ci_pad;
+    }
     a.x = x; a.x_bstride = (int64_t)Ci * T_in; a.Ci = Ci; a.T_in = T_in; a.w = w; a.bias = bias; a.Co = Co; a.ksize = ksize;
     a.dil = dil; a.pad = pad; a.in_act = in_act; a.in_slope = in_slope; a.out = out; a.out_bstride = (int64_t)Co * T_out;
     a.T_out = T_out; a.res = res; a.res_bstride = (int64_t)Co * T_out; a.B = B; a.tr_stride = tr_stride; a.tr_pad = tr_pad; a.tr_k = tr_k;

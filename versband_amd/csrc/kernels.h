@@ -82,6 +82,8 @@ struct ConvArgs {
     int B = 1;
     // transposed convolution (polyphase): stride u > 1
     int tr_stride = 1; int tr_pad = 0; int tr_k = 0;
+    // optional split-bf16 weights [2][phase][tap][Co][Ci_pad] (Ci_pad % 32 == 0): selects the bf16x3 MFMA kernel
+    const bf16_t* wp = nullptr; int64_t wp_plane = 0; int Ci_pad = 0;
 };
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
 

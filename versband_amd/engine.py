@@ -158,8 +158,10 @@ class DiTEngine:
 class NetBuilder:
     """Flattens a conv network into the vb_net_op list executed by the C++ runtime."""
 
-    def __init__(self, device):
+    def __init__(self, device, precision: str = "split"):
+        assert precision in ("split", "fp32")
         self.device = device
+        self.precision = precision      # "split": bf16x3 MFMA conv kernel (fp32-class); "fp32": exact f32 MFMA kernel
         self.ops: List[L.NetOp] = []
         self.bufs: List[Tuple[int, int, int]] = []
         self.free: Dict[Tuple[int, int, int], List[int]] = {}
@@ -196,11 +198,16 @@ class NetBuilder:
              dil: int = 1, pad: int = 0, res: int = -1, stats: int = -1, gamma=None, beta_gn=None, in_act=L.ACT_NONE,
              in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
              acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32):
+        w_x3, ci_pad = None, 0
+        if self.precision == "split" and w is not None and w_buf == -1 and not out_transposed:
+            planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
+            self.keep.append(planes)
+            w_x3 = planes.data_ptr()
         op = L.NetOp(kind=L.OP_CONV, x=x, out=out, res=res, stats=stats, w_buf=w_buf, w=self._t(w), bias=self._t(bias),
                      gn_gamma=self._t(gamma), gn_beta=self._t(beta_gn), Ci=Ci, Co=Co, ksize=k, dil=dil, pad=pad,
                      upsample2=upsample2, in_act=in_act, out_act=out_act, out_transposed=out_transposed, tr_stride=tr_stride,
                      tr_pad=tr_pad, tr_k=tr_k, gn_groups=groups, in_slope=in_slope, out_slope=out_slope, alpha=alpha, beta=beta,
-                     acc_scale=acc_scale)
+                     acc_scale=acc_scale, w_x3=w_x3, ci_pad=ci_pad)
         self.ops.append(op)
 
 
@@ -233,11 +240,11 @@ class ConvNet:
         return out
 
 
-def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float = 1.0) -> ConvNet:
+def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float = 1.0, precision: str = "split") -> ConvNet:
     """AutoencoderKL.decode (autoencoder1d.py:55-58) + Decoder1D.forward (:480-512) as an op list.
     The structure (levels, shortcut convs, attention blocks, which level upsamples) is read off the
     key names, exactly what load_state_dict would accept."""
-    nb = NetBuilder(ctx.device)
+    nb = NetBuilder(ctx.device, precision)
     g = sd
 
     def cw(name):
@@ -322,10 +329,10 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
     return ConvNet(ctx, L.NET_VAE, nb, zc, co, tm)
 
 
-def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict) -> ConvNet:
+def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split") -> ConvNet:
     """HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) as an op list; fully
     driven by the vocoder's config.yaml keys."""
-    nb = NetBuilder(ctx.device)
+    nb = NetBuilder(ctx.device, precision)
 
     def wt(name):
         if name + ".weight" in sd:

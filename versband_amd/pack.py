@@ -49,6 +49,17 @@ def pack_conv_transpose(w: Tensor, stride: int) -> Tensor:
     return out.contiguous()
 
 
+def pack_conv_x3(w_packed: Tensor, ci_multiple: int = 32):
+    """fp32 packed conv weights [..taps.., Ci, Co] -> split-bf16 planes [2, taps, Co, Ci_pad] (Ci contiguous, zero padded
+    to a multiple of 32) for the bf16x3 MFMA conv kernel.  Returns (planes, Ci_pad)."""
+    ci, co = w_packed.shape[-2], w_packed.shape[-1]
+    w = w_packed.reshape(-1, ci, co).permute(0, 2, 1).float()
+    cip = (ci + ci_multiple - 1) // ci_multiple * ci_multiple
+    if cip != ci:
+        w = torch.nn.functional.pad(w, (0, cip - ci))
+    return to_planes(w.contiguous(), 2), cip
+
+
 def fold_weight_norm(g: Tensor, v: Tensor) -> Tensor:
     """weight_norm(dim=0): w = g * v / ||v|| (the reference never removes weight norm:
     vocoder/hifigan/hifigan.py:15-18, so checkpoints carry weight_g / weight_v)."""
