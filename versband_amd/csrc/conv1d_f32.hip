@@ -302,44 +302,66 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
         }
     };
 
-    const int nchunks = (p.Ci + CK3 - 1) / CK3;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int c0 = ch * CK3;
-        // ---- stage the activated window, split to bf16 hi/lo, transposed to [t][ci]; a wave owns ci pairs
-        for (int cp = wave; cp < CK3 / 2; cp += 4) {
-            const int ci0 = c0 + 2 * cp;
-            float gm[2] = {0.f, 0.f}, gr[2] = {1.f, 1.f}, gg[2] = {1.f, 1.f}, gb[2] = {0.f, 0.f};
-            bool cok[2];
+    // ---- activation window staging, split in two halves (async-STAGE): xload() issues ALL global loads of a chunk
+    // into registers (raw values + the per-channel affine of the fused norm), xstore() later applies the pointwise
+    // transform, splits to bf16 hi/lo and writes the transposed image xT[plane][t][ci].  The loads of chunk ch+1 are
+    // in flight while the taps of chunk ch are multiplied.  A wave owns 4 channel pairs of the 32-channel chunk.
+    constexpr int NIT = XW / 64;
+    float raw[4][NIT][2];
+    float nsc[4][2], nsh[4][2];
+    auto xload = [&](int c0) {
+#pragma unroll
+        for (int cpi = 0; cpi < 4; ++cpi) {
+            const int ci0 = c0 + 2 * (wave + 4 * cpi);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                cok[e] = (ci0 + e) < p.Ci;
-                if (cok[e] && (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN)) {
-                    const int grp = (ci0 + e) / cpg;
-                    gm[e] = p.gn_mean[b * p.gn_groups + grp]; gr[e] = p.gn_rstd[b * p.gn_groups + grp];
-                    gg[e] = p.gn_gamma[ci0 + e]; gb[e] = p.gn_beta[ci0 + e];
+                const int ci = ci0 + e;
+                const bool cok = ci < p.Ci;
+                nsc[cpi][e] = 1.f; nsh[cpi][e] = 0.f;
+                if (cok && (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN)) {
+                    const int grp = ci / cpg;
+                    const float rs = p.gn_rstd[b * p.gn_groups + grp] * p.gn_gamma[ci];
+                    nsc[cpi][e] = rs;
+                    nsh[cpi][e] = p.gn_beta[ci] - p.gn_mean[b * p.gn_groups + grp] * rs;
+                }
+                const float* xrow = xbase + (int64_t)(cok ? ci : 0) * p.T_in;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = n0 + in_off + lane + 64 * it;
+                    const bool ok = cok && (lane + 64 * it) < xw_used && idx >= 0 && idx < T_eff;
+                    raw[cpi][it][e] = ok ? xrow[p.upsample2 ? (idx >> 1) : idx] : 0.f;
                 }
             }
-            const float* xrow0 = xbase + (int64_t)(cok[0] ? ci0 : 0) * p.T_in;
-            const float* xrow1 = xbase + (int64_t)(cok[1] ? ci0 + 1 : 0) * p.T_in;
-            for (int wpos = lane; wpos < xw_used; wpos += 64) {
-                const int idx = n0 + in_off + wpos;
-                float v[2] = {0.f, 0.f};
-                if (idx >= 0 && idx < T_eff) {
-                    const int si = p.upsample2 ? (idx >> 1) : idx;
-                    if (cok[0]) v[0] = xrow0[si];
-                    if (cok[1]) v[1] = xrow1[si];
+        }
+    };
+    auto xstore = [&](int c0) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (!cok[e]) continue;
+        for (int cpi = 0; cpi < 4; ++cpi) {
+            const int cp = wave + 4 * cpi;
+            const int ci0 = c0 + 2 * cp;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int wpos = lane + 64 * it;
+                if (wpos >= xw_used) continue;
+                const int idx = n0 + in_off + wpos;
+                const bool inr = idx >= 0 && idx < T_eff;
+                float v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float t = raw[cpi][it][e];
+                    if (inr && (ci0 + e) < p.Ci) {         // zero padding stays zero: the conv pads the ACTIVATED tensor
                         if (p.in_act == ACT_LRELU) {
-                            v[e] = v[e] > 0.f ? v[e] : v[e] * p.in_slope;
+                            t = t > 0.f ? t : t * p.in_slope;
                         } else if (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN) {
-                            v[e] = (v[e] - gm[e]) * gr[e] * gg[e] + gb[e];
-                            if (p.in_act == ACT_GN_SWISH) v[e] = v[e] / (1.f + __expf(-v[e]));
+                            t = t * nsc[cpi][e] + nsh[cpi][e];
+                            if (p.in_act == ACT_GN_SWISH) t = t / (1.f + __expf(-t));
                         }
+                    } else {
+                        t = 0.f;
                     }
+                    v[e] = t;
                 }
-                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                 bf16x2 hi, lo;
                 hi[0] = f2bf(v[0]); hi[1] = f2bf(v[1]);
                 lo[0] = f2bf(v[0] - bf2f(hi[0])); lo[1] = f2bf(v[1] - bf2f(hi[1]));
@@ -347,9 +369,17 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
                 *reinterpret_cast<bf16x2*>(&xT[1][wpos * CKP3 + 2 * cp]) = lo;
             }
         }
+    };
+
+    const int nchunks = (p.Ci + CK3 - 1) / CK3;
+    xload(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * CK3;
+        xstore(c0);
         wload(c0, 0);
         wstore(0);
         __syncthreads();
+        if (ch + 1 < nchunks) xload(c0 + CK3);
         for (int j = 0; j < p.ntaps; ++j) {
             const int buf = j & 1;
             if (j + 1 < p.ntaps) wload(c0, j + 1);
