@@ -4,6 +4,9 @@
 // All are wave64-shaped: one wave per row with float4 lanes where rows are 768 wide.
 #include "kernels.h"
 
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z);
+__device__ __forceinline__ float gumbel_draw(uint64_t seed, int64_t clip, int nfe, int branch, int block, int gate, int t, int width, int e);
+
 // ---------------------------------------------------------------------------
 // RMSNorm * w, then adaLN modulate, written as bf16 planes (feeds the MFMA GEMMs)
 //   RMSNorm  flag_large_dit_moe.py:52-77 ; modulate :80-81
@@ -277,11 +280,18 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
                                                     const float* __restrict__ bg, const float* __restrict__ la, int la_rows,
                                                     const float* __restrict__ hl, int hl_ld, const float* __restrict__ g1,
                                                     const float* __restrict__ g2, const float* __restrict__ g3, int N, int T, int D,
-                                                    int E, int* ic, int* ia, float* mc, float* ma, float* lc_out) {
+                                                    int E, int* ic, int* ia, float* mc, float* ma, float* lc_out, int B, uint64_t seed,
+                                                    int64_t clip_base, int nfe_base, const int* step, int block) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
     const float* x = cq + (int64_t)n * D;
+    // noise source: injected arrays, or draws keyed by (seed, global clip, nfe, branch, block, gate, token)
+    const bool gen = g1 == nullptr;
+    const int bb = n / T, tt = n - bb * T;
+    const int branch = bb / B;
+    const int64_t clip = clip_base + (bb - branch * B);
+    const int nfe = nfe_base + (step ? *step : 0);
     float best = -INFINITY; int bi = 0;
     for (int e = 0; e < E; ++e) {
         float acc = 0.f;
@@ -292,7 +302,7 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
         }
         acc = wave_sum(acc) + bg[e];
         if (lc_out && lane == 0) lc_out[(int64_t)n * E + e] = acc;
-        float z = acc + g2[(int64_t)n * E + e];
+        float z = acc + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 1, tt, E, e) : g2[(int64_t)n * E + e]);
         if (z > best) { best = z; bi = e; }
     }
     if (lane == 0) {
@@ -300,13 +310,13 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
         const float* lar = la + (int64_t)(n % la_rows) * E;
         float bz = -INFINITY; int ba = 0;
         for (int e = 0; e < E; ++e) {
-            float z = lar[e] + g3[(int64_t)n * E + e];
+            float z = lar[e] + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 2, tt, E, e) : g3[(int64_t)n * E + e]);
             if (z > bz) { bz = z; ba = e; }
         }
         ia[n] = ba;
-        const int b = n / T;
-        float z0 = hl[b * hl_ld + 0] + g1[(int64_t)n * 2 + 0];
-        float z1 = hl[b * hl_ld + 1] + g1[(int64_t)n * 2 + 1];
+        const int b = bb;
+        float z0 = hl[b * hl_ld + 0] + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 0, tt, 2, 0) : g1[(int64_t)n * 2 + 0]);
+        float z1 = hl[b * hl_ld + 1] + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 0, tt, 2, 1) : g1[(int64_t)n * 2 + 1]);
         float m = fmaxf(z0, z1);
         float e0 = expf(z0 - m), e1 = expf(z1 - m);
         float inv = 1.f / (e0 + e1);
@@ -316,9 +326,10 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
 }
 int launch_router(const float* cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
-                  float* ma, float* lc_out, hipStream_t st) {
+                  float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
+                  hipStream_t st) {
     hipLaunchKernelGGL(router_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E, ic,
-                       ia, mc, ma, lc_out);
+                       ia, mc, ma, lc_out, B > 0 ? B : 1, seed, clip_base, nfe_base, step, block);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
@@ -415,6 +426,16 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+// Gumbel draw of element (token t, slot e) of stream (seed, clip, nfe, branch, block, gate): counter based, independent
+// of launch geometry, batch slot and world size
+__device__ __forceinline__ float gumbel_draw(uint64_t seed, int64_t clip, int nfe, int branch, int block, int gate, int t, int width, int e) {
+    uint64_t key = splitmix64(seed ^ splitmix64((uint64_t)clip * 0x9E3779B97F4A7C15ull + 0x1234567ull));
+    key = splitmix64(key + (((uint64_t)nfe * 2 + branch) << 20) + ((uint64_t)block << 8) + (uint64_t)gate);
+    uint64_t z = splitmix64(key + ((uint64_t)t * width + e + 1) * 0x9E3779B97F4A7C15ull);
+    float u = (float)((z >> 40) + 1) * (1.0f / 16777218.0f);      // (0,1)
+    float ex = fmaxf(-log1pf(-u), 1e-30f);
+    return -logf(ex);
+}
 // element (row n = (branch*B + b)*T + t, e) of stream (seed, clip_base + b, nfe, branch, block, gate)
 __global__ void fill_gumbel_kernel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base,
                                    int nfe_base, const int* step, int block, int gate) {
@@ -426,13 +447,7 @@ __global__ void fill_gumbel_kernel(float* out, int B, int n_branch, int T, int w
         int64_t row = i / width; int e = (int)(i - row * width);
         int bb = (int)(row / T), t = (int)(row - (int64_t)bb * T);
         int branch = bb / B, b = bb - branch * B;
-        uint64_t key = splitmix64(seed ^ splitmix64((uint64_t)(clip_base + b) * 0x9E3779B97F4A7C15ull + 0x1234567ull));
-        key = splitmix64(key + (((uint64_t)nfe * 2 + branch) << 20) + ((uint64_t)block << 8) + (uint64_t)gate);
-        uint64_t z = splitmix64(key + ((uint64_t)t * width + e + 1) * 0x9E3779B97F4A7C15ull);
-        float u = (float)((z >> 40) + 1) * (1.0f / 16777218.0f);      // (0,1)
-        float ex = -log1pf(-u);
-        ex = fmaxf(ex, 1e-30f);
-        out[i] = -logf(ex);
+        out[i] = gumbel_draw(seed, clip_base + b, nfe, branch, block, gate, t, width, e);
     }
 }
 int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
@@ -526,6 +541,17 @@ __global__ void __launch_bounds__(256) softmax_rows_t_kernel(const float* __rest
 }
 int launch_softmax_rows_t(const float* s, int B, int R, int Ccols, float* out_t, hipStream_t st) {
     hipLaunchKernelGGL(softmax_rows_t_kernel, dim3(cdiv(R, 4), B), dim3(256), 0, st, s, R, Ccols, out_t);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// out[i] = i / div   (row -> step index of the tabulated conditioning vectors)
+__global__ void iota_div_kernel(int64_t* out, int n, int div) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i / div;
+}
+int launch_iota_div(int64_t* out, int n, int div, hipStream_t st) {
+    hipLaunchKernelGGL(iota_div_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, out, n, div);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

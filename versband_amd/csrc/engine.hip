@@ -98,9 +98,11 @@ static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T
     return o;
 }
 
+#define PRE_STEPS 64      // sampler steps whose adaLN / gate vectors are tabulated up front
 struct WsL {
     int* step; int64_t* t_idx_cur; int64_t* t_table; float* dt_table;
     float *temb0, *temb, *mod_all, *hl, *h, *cq32, *mc, *ma, *y32, *g1, *g2, *g3, *v;
+    float *temb0_s, *temb_s, *hl_s, *mod_s; int64_t* row_step;     // per-sample tables of the conditioning vectors of every step
     bf16_t *u, *q, *k, *vt, *a, *qm, *cqa, *Hs, *y, *Hf;
     int *ic, *ia, *group_off, *perm;
     // precompute temporaries
@@ -163,6 +165,11 @@ static WsL carve_ws(void* base, const vb_dit_config& c, int B, int nb, int T, in
     o.yp = cv.take<bf16_t>(NL * D * 2);
     o.pooled = cv.take<float>((size_t)Beff * D);
     o.pooled_ln = cv.take<float>((size_t)Beff * D);
+    o.temb0_s = cv.take<float>((size_t)PRE_STEPS * D);
+    o.temb_s = cv.take<float>((size_t)PRE_STEPS * D);
+    o.hl_s = cv.take<float>((size_t)PRE_STEPS * c.depth * 2);
+    o.mod_s = cv.take<float>((size_t)PRE_STEPS * Beff * o.MODW);
+    o.row_step = cv.take<int64_t>((size_t)PRE_STEPS * Beff);
     o.total = cv.off;
     return o;
 }
@@ -253,7 +260,7 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
 // ------------------------------------------------------------------------------------------
 static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int noise_step,
                        const int* step_ptr, int B, int nb, int T, int L, float* v_out, int32_t* route_out, void* ws, bool zero_vt,
-                       hipStream_t st) {
+                       const float* pre_mod, const float* pre_hl, hipStream_t st) {
     const vb_dit_config& c = ctx->cfg;
     const vb_dit_weights& w = ctx->w;
     CondL cd = carve_cond(const_cast<void*>(cond), c, B, nb, T, L);
@@ -266,10 +273,16 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     if (zero_vt) VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * np * sizeof(bf16_t), st));
 
     // ---- timestep embedding + all adaLN modulations + high-level gate logits (depend on (t, caption) only)
-    VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, t_idx, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, Beff, D, 256, 0, s.temb0, D, st));
-    VB_TRY(launch_gemv_rows(s.temb0, D, nullptr, 0, 1, w.t_mlp2_w, w.t_mlp2_b, Beff, D, D, 1, s.temb, D, st));
-    VB_TRY(launch_gemv_rows(s.temb, D, cd.cemb, D, Beff, w.adaln_w, w.adaln_b, Beff, MODW, D, 1, s.mod_all, MODW, st));
-    VB_TRY(launch_gemv_rows(s.temb, D, nullptr, 0, 1, w.hl_w, w.hl_b, Beff, c.depth * 2, D, 0, s.hl, c.depth * 2, st));
+    // (the sampler tabulates them for all steps up front and passes this step's rows in pre_mod / pre_hl)
+    const float* mod_all = s.mod_all; const float* hl = s.hl; int hl_ld = c.depth * 2;
+    if (pre_mod) {
+        mod_all = pre_mod; hl = pre_hl; hl_ld = 0;
+    } else {
+        VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, t_idx, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, Beff, D, 256, 0, s.temb0, D, st));
+        VB_TRY(launch_gemv_rows(s.temb0, D, nullptr, 0, 1, w.t_mlp2_w, w.t_mlp2_b, Beff, D, D, 1, s.temb, D, st));
+        VB_TRY(launch_gemv_rows(s.temb, D, cd.cemb, D, Beff, w.adaln_w, w.adaln_b, Beff, MODW, D, 1, s.mod_all, MODW, st));
+        VB_TRY(launch_gemv_rows(s.temb, D, nullptr, 0, 1, w.hl_w, w.hl_b, Beff, c.depth * 2, D, 0, s.hl, c.depth * 2, st));
+    }
 
     // ---- h = proj_in(x)^T + acoustic   (vocal2music_moe.py:395,415)
     {
@@ -288,7 +301,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
 
     for (int i = 0; i < c.depth; ++i) {
         const vb_dit_block_weights& bw = w.blocks[i];
-        const float* mod = s.mod_all + (size_t)i * 6 * D;    // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        const float* mod = mod_all + (size_t)i * 6 * D;    // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
         // ---- attention (flag_large_dit_moe.py:323-406)
         VB_TRY(launch_rmsnorm_mod(s.h, bw.attn_norm_w, mod, mod + D, MODW, N, D, T, c.norm_eps, u, st));
         GemmArgs g;
@@ -323,21 +336,14 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         g.M = N; g.N = D; g.K = D; g.nseg = nseg; g.epi = EPI_F32; g.bias = bw.bo_m; g.out32 = s.cq32; g.ldc32 = D;
         VB_TRY(launch_gemm(g, st));
         // gates
-        const float *g1, *g2, *g3;
+        // gates: injected Gumbel arrays (parity path) or counter-based draws generated inside the router kernel
+        const float *g1 = nullptr, *g2 = nullptr, *g3 = nullptr;
         if (noise && noise->g1) {
             const size_t so = (size_t)noise_step * c.depth + i;
             g1 = noise->g1 + so * N * 2; g2 = noise->g2 + so * N * E; g3 = noise->g3 + so * N * E;
-        } else {
-            const uint64_t seed = noise ? noise->seed : 0;
-            const int64_t clip = noise ? noise->clip_base : 0;
-            const int nfe0 = noise ? noise->nfe : 0;
-            VB_TRY(launch_fill_gumbel(s.g1, B, nb, T, 2, seed, clip, nfe0, step_ptr, i, 0, st));
-            VB_TRY(launch_fill_gumbel(s.g2, B, nb, T, E, seed, clip, nfe0, step_ptr, i, 1, st));
-            VB_TRY(launch_fill_gumbel(s.g3, B, nb, T, E, seed, clip, nfe0, step_ptr, i, 2, st));
-            g1 = s.g1; g2 = s.g2; g3 = s.g3;
         }
-        VB_TRY(launch_router(s.cq32, bw.wcg, bw.bcg, cd.la[i], B * T, s.hl + i * 2, c.depth * 2, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
-                             s.ma, nullptr, st));
+        VB_TRY(launch_router(s.cq32, bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
+                             s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st));
         VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -371,7 +377,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         VB_TRY(launch_gemm(g, st));
     }
     // ---- FinalLayer (vocal2music_moe.py:287-291) -> v [Beff][C][T]
-    const float* modf = s.mod_all + (size_t)c.depth * 6 * D;
+    const float* modf = mod_all + (size_t)c.depth * 6 * D;
     VB_TRY(launch_final_layer(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, v_out, st));
     return VB_OK;
 }
@@ -531,7 +537,8 @@ int vb_dit_precompute_cond(vb_ctx* ctx, const float* t5, const int64_t* midi, co
 int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int B, int n_branch,
                    int T, int L, float* v_out, int32_t* route_out, void* ws, void* stream) {
     if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "dit_forward: DiT not loaded");
-    return dit_forward(ctx, x, t_idx, cond, noise, 0, nullptr, B, n_branch, T, L, v_out, route_out, ws, true, (hipStream_t)stream);
+    return dit_forward(ctx, x, t_idx, cond, noise, 0, nullptr, B, n_branch, T, L, v_out, route_out, ws, true, nullptr, nullptr,
+                       (hipStream_t)stream);
 }
 int vb_euler_cfg_step(float* x, const float* v, int B, int64_t per_item, float cfg_scale, float dt, int has_uncond, void* stream) {
     return launch_euler_cfg(x, v, B, per_item, cfg_scale, nullptr, nullptr, dt, has_uncond, (hipStream_t)stream);
@@ -550,9 +557,23 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
     VB_HIP(hipMemcpyAsync(s.dt_table, dt_table, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, st));
     VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * c.np * sizeof(bf16_t), st));
     if (traj) VB_HIP(hipMemcpyAsync(traj, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // The timestep embedding, every block's adaLN modulation and the high-level gate logits depend on (t_k, caption)
+    // only: tabulate them for ALL steps in four launches instead of four GEMVs inside every network evaluation.
+    const bool tab = n_steps <= PRE_STEPS;
+    const int D = c.hidden, MODW = s.MODW;
+    if (tab) {
+        const vb_dit_weights& w = ctx->w;
+        CondL cd = carve_cond(const_cast<void*>(cond), c, B, n_branch, T, L);
+        VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, s.t_table, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, n_steps, D, 256, 0, s.temb0_s, D, st));
+        VB_TRY(launch_gemv_rows(s.temb0_s, D, nullptr, 0, 1, w.t_mlp2_w, w.t_mlp2_b, n_steps, D, D, 1, s.temb_s, D, st));
+        VB_TRY(launch_iota_div(s.row_step, n_steps * Beff, Beff, st));
+        VB_TRY(launch_gemv_rows_idx(s.temb_s, D, s.row_step, cd.cemb, D, Beff, w.adaln_w, w.adaln_b, n_steps * Beff, MODW, D, 1, s.mod_s, MODW, st));
+        VB_TRY(launch_gemv_rows(s.temb_s, D, nullptr, 0, 1, w.hl_w, w.hl_b, n_steps, c.depth * 2, D, 0, s.hl_s, c.depth * 2, st));
+    }
     for (int k = 0; k < n_steps; ++k) {
         VB_TRY(launch_step_ctl(s.step, s.t_idx_cur, s.t_table, n_steps, Beff, k == 0, st));
-        VB_TRY(dit_forward(ctx, x, s.t_idx_cur, cond, noise, k, s.step, B, n_branch, T, L, s.v, nullptr, ws, false, st));
+        VB_TRY(dit_forward(ctx, x, s.t_idx_cur, cond, noise, k, s.step, B, n_branch, T, L, s.v, nullptr, ws, false,
+                           tab ? s.mod_s + (size_t)k * Beff * MODW : nullptr, tab ? s.hl_s + (size_t)k * c.depth * 2 : nullptr, st));
         VB_TRY(launch_euler_cfg(x, s.v, B, per, cfg_scale, s.dt_table, s.step, 0.f, n_branch == 2, st));
         if (traj) VB_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * B * per, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
     }

@@ -110,7 +110,9 @@ int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_sca
                      float dt_val, int has_uncond, hipStream_t st);
 int launch_router(const float* cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
-                  float* ma, float* lc_out, hipStream_t st);
+                  float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
+                  hipStream_t st);
+int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st);
 int launch_router_top1(const float* logits, const float* gumbel, int N, int E, int* idx, hipStream_t st);
 int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
