@@ -86,6 +86,7 @@ typedef struct {
     const float* adaln_w; const float* adaln_b;   /* stacked [depth*6D + 2D][D]: blocks' adaLN then final_layer's */
     const float* hl_w; const float* hl_b;         /* stacked high_level_gating_network [depth*2][D] */
     const float* proj_in_w; const float* proj_in_b;  /* conv packed [5][C][D] */
+    const void* proj_in_w3;                          /* same weights as split-bf16 planes [2][5][D][32] (bf16x3 conv kernel) */
     const float* final_w; const float* final_b;      /* final_layer.linear [C][D] */
     const float* rope_cos; const float* rope_sin;    /* [max_len][hd/2]  precompute_freqs_cis */
     /* precompute only */

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
     constexpr int NP = SPLIT ? 2 : 1;
     __shared__ __attribute__((aligned(16))) bf16_t Kl[NP][KT * KPITCH];
     __shared__ __attribute__((aligned(16))) bf16_t Vl[NP][HD * VPITCH];
+    __shared__ float stash[4][48][64];     // the cross-attention result waits here while self-attention runs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5, ql = lane & 31;
@@ -61,43 +62,63 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
         }
     }
 
-    f32x16 o[3], oc[3];
+    f32x16 o[3];
     float res_l = 1.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[i][r] = 0.f; oc[i][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
     auto kv_pass = [&](const bf16_t* Kg, int64_t kplane, const bf16_t* Vg, int64_t vplane, int nkeys, int vpad, int kb_batch,
                        f32x16 (&acc)[3], float& l_out) __attribute__((always_inline)) {
         float m_run = -1e30f, l_run = 0.f;
         const int ntiles = (nkeys + KT - 1) / KT;
+        // register prefetch (bf16 mode): the global loads of tile kt+1 are issued before tile kt is multiplied and
+        // written to LDS after it, so their latency hides behind the MFMAs (split mode has no registers to spare)
+        uint4 kreg[3], vreg[3];
+        auto tile_load = [&](int kt, uint4 (&kr)[3], uint4 (&vr)[3], int pl) {
+            const int key0 = kt * KT;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int id = tid + i * 256;
+                const int key = id / 12, c = id - key * 12;
+                const bool ok = (key0 + key) < nkeys;
+                const bf16_t* src = Kg + ((int64_t)kb_batch * nkeys + (ok ? key0 + key : 0)) * p.D + h * HD + c * 8;
+                kr[i] = ok ? *reinterpret_cast<const uint4*>(src + pl * kplane) : make_uint4(0, 0, 0, 0);
+                const int d = id >> 3, c2 = id & 7;
+                const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + d) * vpad + key0 + c2 * 8;
+                vr[i] = *reinterpret_cast<const uint4*>(vs + pl * vplane);
+            }
+        };
+        auto tile_store = [&](const uint4 (&kr)[3], const uint4 (&vr)[3], int pl) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int id = tid + i * 256;
+                const int key = id / 12, c = id - key * 12;
+                *reinterpret_cast<uint4*>(&Kl[pl][key * KPITCH + c * 8]) = kr[i];
+                const int d = id >> 3, c2 = id & 7;
+                uint2* dst = reinterpret_cast<uint2*>(&Vl[pl][d * VPITCH + c2 * 8]);
+                dst[0] = make_uint2(vr[i].x, vr[i].y);
+                dst[1] = make_uint2(vr[i].z, vr[i].w);
+            }
+        };
+        if constexpr (!SPLIT) tile_load(0, kreg, vreg, 0);
         for (int kt = 0; kt < ntiles; ++kt) {
             const int key0 = kt * KT;
             __syncthreads();
-            // ---- stage K tile [64 keys][96] and V^T tile [96][64 keys]
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                int id = tid + i * 256;
-                int key = id / 12, c = id - key * 12;
-                bool ok = (key0 + key) < nkeys;
-                const bf16_t* src = Kg + ((int64_t)kb_batch * nkeys + (ok ? key0 + key : 0)) * p.D + h * HD + c * 8;
+            if constexpr (!SPLIT) {
+                tile_store(kreg, vreg, 0);
+            } else {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
-                    uint4 v = ok ? *reinterpret_cast<const uint4*>(src + pl * kplane) : make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4*>(&Kl[pl][key * KPITCH + c * 8]) = v;
-                }
-                int d = id >> 3, c2 = id & 7;
-                const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + d) * vpad + key0 + c2 * 8;
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-                    uint4 v = *reinterpret_cast<const uint4*>(vs + pl * vplane);
-                    uint2* dst = reinterpret_cast<uint2*>(&Vl[pl][d * VPITCH + c2 * 8]);
-                    dst[0] = make_uint2(v.x, v.y);
-                    dst[1] = make_uint2(v.z, v.w);
+                    tile_load(kt, kreg, vreg, pl);
+                    tile_store(kreg, vreg, pl);
                 }
             }
             __syncthreads();
+            if constexpr (!SPLIT) {
+                if (kt + 1 < ntiles) tile_load(kt + 1, kreg, vreg, 0);
+            }
             // ---- S^T = K Q^T  (two 32-key sub-tiles)
             f32x16 s[2];
 #pragma unroll
@@ -179,23 +200,31 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
         l_out = l_run + __shfl_xor(l_run, 32, 64);
     };
 
+    // cross attention first (2 short tiles); its weighted, normalised result is parked in LDS so the long
+    // self-attention pass runs with a single accumulator set (keeps the kernel at 2 waves per SIMD)
+    if (p.has_cross) {
+        float lc;
+        const int kb_batch = p.kv_batch_mod > 0 ? (b % p.kv_batch_mod) : b;
+        kv_pass(p.ky, p.ky_plane, p.vyt, p.vyt_plane, p.L, p.Lpad, kb_batch, o, lc);
+        const float w = (p.cross_w ? p.cross_w[h] : 1.f) / lc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= w;
+    }
     if (p.has_self) {
+        if (p.has_cross) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { stash[wave][i * 16 + r][lane] = o[i][r]; o[i][r] = 0.f; }
+        }
         kv_pass(p.k, p.k_plane, p.vt, p.vt_plane, p.T, p.Tpad, b, o, res_l);
         const float inv = 1.f / res_l;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= inv;
-    }
-    if (p.has_cross) {
-        float lc;
-        const int kb_batch = p.kv_batch_mod > 0 ? (b % p.kv_batch_mod) : b;
-        kv_pass(p.ky, p.ky_plane, p.vyt, p.vyt_plane, p.L, p.Lpad, kb_batch, oc, lc);
-        const float w = (p.cross_w ? p.cross_w[h] : 1.f) / lc;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] += w * oc[i][r];
+            for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * inv + (p.has_cross ? stash[wave][i * 16 + r][lane] : 0.f);
     }
     if (qrow < p.T) {
         const int64_t base = ((int64_t)b * p.T + qrow) * p.D + h * HD;

@@ -292,6 +292,13 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
     const int branch = bb / B;
     const int64_t clip = clip_base + (bb - branch * B);
     const int nfe = nfe_base + (step ? *step : 0);
+    // lanes [0,E): caption-gate draws, [E,2E): acoustic-gate draws, 2E, 2E+1: high-level gate draws (one draw per lane)
+    float my_draw = 0.f;
+    if (gen && lane < 2 * E + 2) {
+        const int gate = lane < E ? 1 : (lane < 2 * E ? 2 : 0);
+        const int slot = lane < E ? lane : (lane < 2 * E ? lane - E : lane - 2 * E);
+        my_draw = gumbel_draw(seed, clip, nfe, branch, block, gate, tt, gate == 0 ? 2 : E, slot);
+    }
     float best = -INFINITY; int bi = 0;
     for (int e = 0; e < E; ++e) {
         float acc = 0.f;
@@ -302,21 +309,25 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
         }
         acc = wave_sum(acc) + bg[e];
         if (lc_out && lane == 0) lc_out[(int64_t)n * E + e] = acc;
-        float z = acc + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 1, tt, E, e) : g2[(int64_t)n * E + e]);
+        float z = acc + (gen ? __shfl(my_draw, e, 64) : g2[(int64_t)n * E + e]);
         if (z > best) { best = z; bi = e; }
     }
+    float d3[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d3[e] = (gen && e < E) ? __shfl(my_draw, E + e, 64) : 0.f;
+    const float d10 = gen ? __shfl(my_draw, 2 * E, 64) : 0.f, d11 = gen ? __shfl(my_draw, 2 * E + 1, 64) : 0.f;
     if (lane == 0) {
         ic[n] = bi;
         const float* lar = la + (int64_t)(n % la_rows) * E;
         float bz = -INFINITY; int ba = 0;
         for (int e = 0; e < E; ++e) {
-            float z = lar[e] + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 2, tt, E, e) : g3[(int64_t)n * E + e]);
+            float z = lar[e] + (gen ? d3[e] : g3[(int64_t)n * E + e]);
             if (z > bz) { bz = z; ba = e; }
         }
         ia[n] = ba;
         const int b = bb;
-        float z0 = hl[b * hl_ld + 0] + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 0, tt, 2, 0) : g1[(int64_t)n * 2 + 0]);
-        float z1 = hl[b * hl_ld + 1] + (gen ? gumbel_draw(seed, clip, nfe, branch, block, 0, tt, 2, 1) : g1[(int64_t)n * 2 + 1]);
+        float z0 = hl[b * hl_ld + 0] + (gen ? d10 : g1[(int64_t)n * 2 + 0]);
+        float z1 = hl[b * hl_ld + 1] + (gen ? d11 : g1[(int64_t)n * 2 + 1]);
         float m = fmaxf(z0, z1);
         float e0 = expf(z0 - m), e1 = expf(z1 - m);
         float inv = 1.f / (e0 + e1);

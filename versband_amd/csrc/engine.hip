@@ -289,6 +289,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         ConvArgs cv;
         cv.x = x; cv.x_bstride = (int64_t)c.in_channels * T; cv.Ci = c.in_channels; cv.T_in = T; cv.x_bmod = B;
         cv.w = w.proj_in_w; cv.bias = w.proj_in_b; cv.Co = D; cv.ksize = 5; cv.pad = 2;
+        if (w.proj_in_w3 && c.in_channels <= 32) { cv.wp = (const bf16_t*)w.proj_in_w3; cv.Ci_pad = 32; cv.wp_plane = (int64_t)5 * D * 32; }
         cv.out = s.h; cv.out_bstride = (int64_t)T * D; cv.T_out = T; cv.out_transposed = 1;
         cv.add = cd.ac; cv.add_bstride = (int64_t)T * D; cv.add_bmod = B; cv.B = Beff;
         VB_TRY(launch_conv1d(cv, st));

@@ -99,6 +99,7 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
     top["hl_w"] = torch.cat([g(f"blocks.{i}.feed_forward.high_level_gating_network.weight") for i in range(cfg.depth)]).contiguous()
     top["hl_b"] = torch.cat([g(f"blocks.{i}.feed_forward.high_level_gating_network.bias") for i in range(cfg.depth)]).contiguous()
     top["proj_in_w"], top["proj_in_b"] = pack_conv(g("proj_in.weight")), g("proj_in.bias")
+    top["proj_in_w3"] = pack_conv_x3(top["proj_in_w"])[0]
     top["final_w"], top["final_b"] = g("final_layer.linear.weight"), g("final_layer.linear.bias")
     cos, sin = rope_tables(cfg.head_dim, cfg.max_len)
     top["rope_cos"], top["rope_sin"] = cos.to(device), sin.to(device)
