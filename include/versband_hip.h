@@ -62,7 +62,7 @@ typedef struct {
     const void* wqkv;   /* [3D][D]  rows wq|wk|wv              flag_large_dit_moe.py:173-181 */
     const void* wo;     /* [D][D]                               :193 */
     const void* wq_m;   /* MoE.cross_attention in_proj rows 0:D vocal2music_moe.py:79 */
-    const void* wo_m;   /* MoE.cross_attention.out_proj */
+    const void* wo_m;   /* MoE.cross_attention.out_proj (kept for reference; folded into wcg/bcg, no GEMM runs on it) */
     const void* w13;    /* [2E][2H][D] routed experts, rows interleaved w1_0,w3_0,w1_1,...  (caption group first) */
     const void* w2;     /* [2E][D][H] */
     const void* w13f;   /* [E][2H][band]  band experts restricted to their channel band (:171-178) */
@@ -75,7 +75,7 @@ typedef struct {
     const float* bq_m; const float* bo_m; const float* bk_m; const float* bv_m;
     const float* attn_norm_w; const float* ffn_norm_w; const float* y_norm_w;
     const float* cross_w;            /* tanh(attention.gate) [heads]   :401 */
-    const float* wcg; const float* bcg;   /* caption_gating_network  [E][D],[E] */
+    const float* wcg; const float* bcg;   /* caption_gating_network with cross_attention.out_proj folded in: Wg*Wo [E][D], Wg*bo+bg [E] */
     const float* wag; const float* bag;   /* acoustic_gating_network (precompute only) */
 } vb_dit_block_weights;
 

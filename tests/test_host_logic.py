@@ -85,6 +85,12 @@ def test_pack_dit_layouts():
     assert pk["top"]["adaln_w"].shape == (cfg.depth * 6 * D + 2 * D, D)
     assert torch.equal(pk["top"]["t_freq_table"][416], ref_cpu.timestep_embedding(torch.tensor([416]))[0])
     assert torch.allclose(b0["cross_w"], torch.tanh(sd["blocks.0.attention.gate"]))
+    # out_proj folded into the caption gate: same logits as the two chained linears
+    a = torch.from_numpy(prng.normal(5, 7 * D)).reshape(7, D)
+    p0 = "blocks.0.feed_forward."
+    chained = F.linear(F.linear(a, sd[p0 + "cross_attention.out_proj.weight"], sd[p0 + "cross_attention.out_proj.bias"]),
+                       sd[p0 + "caption_gating_network.weight"], sd[p0 + "caption_gating_network.bias"])
+    assert torch.allclose(F.linear(a, b0["wcg"], b0["bcg"]), chained, atol=2e-6)
 
 
 def test_factory_and_checkpoint_plumbing(tmp_path):

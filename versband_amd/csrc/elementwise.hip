@@ -276,7 +276,7 @@ int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n
 //   lc = cq . Wg^T + bg ; ic = argmax(lc + G2) ; ia = argmax(la + G3) (first maximum wins, like
 //   torch.max) ; (m_c, m_a) = softmax(hl[b] + G1).   G* are Gumbel draws (-log Exp(1)).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ cq, const float* __restrict__ Wg,
+__global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __restrict__ Wg,
                                                     const float* __restrict__ bg, const float* __restrict__ la, int la_rows,
                                                     const float* __restrict__ hl, int hl_ld, const float* __restrict__ g1,
                                                     const float* __restrict__ g2, const float* __restrict__ g3, int N, int T, int D,
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
-    const float* x = cq + (int64_t)n * D;
+    const bf16_t* xh = cq.p + (int64_t)n * D;
     // noise source: injected arrays, or draws keyed by (seed, global clip, nfe, branch, block, gate, token)
     const bool gen = g1 == nullptr;
     const int bb = n / T, tt = n - bb * T;
@@ -299,13 +299,35 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
         const int slot = lane < E ? lane : (lane < 2 * E ? lane - E : lane - 2 * E);
         my_draw = gumbel_draw(seed, clip, nfe, branch, block, gate, tt, gate == 0 ? 2 : E, slot);
     }
+    // token features = MoE cross-attention output (bf16 planes); Wg/bg already contain out_proj folded in
+    float xv[12];      // D <= 768: 3 x 4 values per lane
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = lane * 4 + i * 256;
+        if (k < D) {
+            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(xh + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[i * 4 + j] = bf2f(hv[j]);
+            if (cq.np == 2) {
+                const bf16x4 lv = *reinterpret_cast<const bf16x4*>(xh + cq.plane + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[i * 4 + j] += bf2f(lv[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[i * 4 + j] = 0.f;
+        }
+    }
     float best = -INFINITY; int bi = 0;
     for (int e = 0; e < E; ++e) {
         float acc = 0.f;
-        for (int k = lane * 4; k < D; k += 256) {
-            float4 xv = *reinterpret_cast<const float4*>(x + k);
-            float4 wv = *reinterpret_cast<const float4*>(Wg + (int64_t)e * D + k);
-            acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (k < D) {
+                const float4 wv = *reinterpret_cast<const float4*>(Wg + (int64_t)e * D + k);
+                acc += xv[i * 4] * wv.x + xv[i * 4 + 1] * wv.y + xv[i * 4 + 2] * wv.z + xv[i * 4 + 3] * wv.w;
+            }
         }
         acc = wave_sum(acc) + bg[e];
         if (lc_out && lane == 0) lc_out[(int64_t)n * E + e] = acc;
@@ -335,7 +357,7 @@ __global__ void __launch_bounds__(256) router_kernel(const float* __restrict__ c
         ma[n] = e1 * inv;
     }
 }
-int launch_router(const float* cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
+int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
                   hipStream_t st) {

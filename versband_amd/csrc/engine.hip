@@ -332,18 +332,15 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         at.vyt = mkp(cd.vct[i], cd.n_vt, np); at.cross_w = nullptr; at.out = cqa; at.B = Beff; at.T = T; at.Tpad = s.Tpad; at.L = L;
         at.Lpad = cd.Lpad; at.H = c.heads; at.hd = hd; at.has_self = 0; at.has_cross = 1; at.kv_batch_mod = 0; at.scale = scale;
         VB_TRY(launch_attention(at, st));
-        g = GemmArgs();
-        g.A = cqa.p; g.a_plane = ND; g.lda = D; g.B = (const bf16_t*)bw.wo_m; g.b_plane = (int64_t)D * D; g.ldb = D;
-        g.M = N; g.N = D; g.K = D; g.nseg = nseg; g.epi = EPI_F32; g.bias = bw.bo_m; g.out32 = s.cq32; g.ldc32 = D;
-        VB_TRY(launch_gemm(g, st));
-        // gates
+        // (MoE.cross_attention.out_proj is folded into the caption gate at pack time: lc = cqa . (Wcg Wo)^T + (Wcg bo + bcg),
+        //  so the [N,768]x[768,768] out_proj GEMM never runs - its only consumer is the 768->E gate, vocal2music_moe.py:119-141)
         // gates: injected Gumbel arrays (parity path) or counter-based draws generated inside the router kernel
         const float *g1 = nullptr, *g2 = nullptr, *g3 = nullptr;
         if (noise && noise->g1) {
             const size_t so = (size_t)noise_step * c.depth + i;
             g1 = noise->g1 + so * N * 2; g2 = noise->g2 + so * N * E; g3 = noise->g3 + so * N * E;
         }
-        VB_TRY(launch_router(s.cq32, bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
+        VB_TRY(launch_router(cqa, bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
                              s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st));
         VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st));
         if (route_out) {
@@ -518,6 +515,7 @@ int vb_dit_load(vb_ctx* ctx, const vb_dit_config* cfg, const vb_dit_weights* w) 
     if (cfg->hidden % cfg->num_experts || (cfg->hidden / cfg->num_experts) % 8) VB_FAIL(VB_E_INVALID, "dit_load: band width must be a multiple of 8");
     if (cfg->context_dim != cfg->hidden) VB_FAIL(VB_E_INVALID, "dit_load: context_dim must equal hidden_size (vocal2music_moe.py:367-373)");
     if (cfg->num_experts > 16) VB_FAIL(VB_E_INVALID, "dit_load: num_experts %d > 16", cfg->num_experts);
+    if (cfg->hidden > 768) VB_FAIL(VB_E_INVALID, "dit_load: hidden %d > 768 (router register tile)", cfg->hidden);
     ctx->cfg = *cfg;
     ctx->w = *w;
     ctx->dit_loaded = true;

@@ -108,7 +108,7 @@ int launch_final_layer(const float* h, const float* shift, const float* scale, i
                        int rows, int D, int T, int C, float eps, float* out, hipStream_t st);
 int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_scale, const float* dt_table, const int* step,
                      float dt_val, int has_uncond, hipStream_t st);
-int launch_router(const float* cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
+int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
                   hipStream_t st);

@@ -142,7 +142,11 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
         b["attn_norm_w"], b["ffn_norm_w"] = g(p + "attention_norm.weight"), g(p + "ffn_norm.weight")
         b["y_norm_w"] = g(p + "attention_y_norm.weight")
         b["cross_w"] = torch.tanh(g(p + "attention.gate")).contiguous()
-        b["wcg"], b["bcg"] = g(p + "feed_forward.caption_gating_network.weight"), g(p + "feed_forward.caption_gating_network.bias")
+        # caption gate with MoE.cross_attention.out_proj folded in (the gate is the out_proj's only consumer):
+        #   logits = (a Wo^T + bo) Wg^T + bg = a (Wg Wo)^T + (Wg bo + bg)          (vocal2music_moe.py:119-141)
+        wg, bgate = g(p + "feed_forward.caption_gating_network.weight").double(), g(p + "feed_forward.caption_gating_network.bias").double()
+        wo_m, bo_m = g(p + "feed_forward.cross_attention.out_proj.weight").double(), g(p + "feed_forward.cross_attention.out_proj.bias").double()
+        b["wcg"], b["bcg"] = (wg @ wo_m).float().contiguous(), (wg @ bo_m + bgate).float().contiguous()
         b["wag"], b["bag"] = g(p + "feed_forward.acoustic_gating_network.weight"), g(p + "feed_forward.acoustic_gating_network.bias")
         blocks.append(b)
     return {"top": top, "blocks": blocks}
