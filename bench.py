@@ -53,6 +53,31 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+CLASS_KERNELS = {0: ("gemm_bf16",), 1: ("attn_kernel",), 2: ("conv1d_",)}
+
+
+def pmc_traffic(cls):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; counter unit = KB; FETCH_SIZE doubled for
+    gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        tot, n = 0.0, 0
+        for name, v in d.get("FETCH_SIZE", {}).items():
+            if any(k in name for k in CLASS_KERNELS[cls]):
+                tot += 2.0 * v["sum_kb"] * 1024.0
+                n += v["launches"]
+        for name, v in d.get("WRITE_SIZE", {}).items():
+            if any(k in name for k in CLASS_KERNELS[cls]):
+                tot += v["sum_kb"] * 1024.0
+        return (tot / n) if n else None
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,7 +299,9 @@ def main():
                        "clips_per_gpu": B, "flow_steps": args.flow_steps, "precision": args.precision,
                        "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": pmc_traffic(dominant),
+                         "traffic_note": "HBM bytes per launch averaged over the class, from the committed rocprofv3 --pmc FETCH_SIZE / "
+                                         "WRITE_SIZE passes of this command (profiles/r01_pmc_summary.json); algorithmic bytes in DESIGN.md",
                          "avg_launch_us": (1e3 * ms / nt) if nt else None, "launches_per_step": n / max(args.steps, 1),
                          "class_ms_per_step_warmup": {PEAK[c][2]: round(v, 3) for c, v in breakdown.items()}},
         }

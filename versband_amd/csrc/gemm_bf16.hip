@@ -286,7 +286,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "unsupported vmcnt");
 }
 
-template <int EPI, int BKT, int NST>
+// ABL (tuning only): 1 = no tile DMA in the loop, 2 = no MFMA, 3 = no LDS fragment reads
+template <int EPI, int BKT, int NST, int ABL = 0>
 __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev p) {
     constexpr int CH = BKT / 8;              // 16-B chunks per tile row
     constexpr int RS = 64 / CH;              // tile rows covered by one wave-wide DMA (1 KB)
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         }
     }
     const int n0 = tile_n * BN;
-    const int KT = p.K / BKT;
+    const int KT = (ABL == 5) ? 0 : p.K / BKT;
     const int total = KT * p.nseg;
 
     const bf16_t* asrc[SPW]; const bf16_t* bsrc[SPW];
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         else if (NST >= 3 && ahead >= 1) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();           // tile t landed everywhere; everyone finished reading stage (t-1)%NST
-        if (t + NST - 1 < total) issue(t + NST - 1);
+        if (ABL != 1 && t + NST - 1 < total) issue(t + NST - 1);
         const unsigned char* As = &lds[(st * 2 + 0) * OPB];
         const unsigned char* Bs = &lds[(st * 2 + 1) * OPB];
 #pragma unroll
@@ -383,14 +384,25 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
             const int c = ks * 2 + fk;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
-                bf[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
+                if constexpr (ABL == 3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { af[i][e] = (bf16_t)(float)(t + e); bf[i][e] = (bf16_t)(float)(ks + e); }
+                } else {
+                    af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
+                    bf[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (ABL == 2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[i][j][e] += (float)af[i][e] * (float)bf[j][e];
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+                }
         }
     }
 
@@ -405,7 +417,11 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
                 int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
                 if (n >= p.N) continue;
                 float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                epilogue4<EPI>(p, g, slot, n, v);
+                if constexpr (ABL == 4) {
+                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));     // keep the accumulators alive, store nothing
+                } else {
+                    epilogue4<EPI>(p, g, slot, n, v);
+                }
             }
         }
     }
@@ -417,6 +433,15 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     // 4 DMA BK=64 x3 stages.  Default 1 (fastest on the DiT shapes, tools/gemm_bench.py).
     const char* ev = getenv("VB_GEMM_VARIANT");
     const int variant = ev ? atoi(ev) : 1;
+    const char* ea = getenv("VB_GEMM_ABLATE");
+    const int abl = ea ? atoi(ea) : 0;
+    if constexpr (EPI == EPI_F32) {
+        if (abl == 1 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 1>), grid, dim3(NTHREADS), 0, st, d); return; }
+        if (abl == 2 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 2>), grid, dim3(NTHREADS), 0, st, d); return; }
+        if (abl == 3 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
+        if (abl == 4 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 4>), grid, dim3(NTHREADS), 0, st, d); return; }
+        if (abl == 5 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 5>), grid, dim3(NTHREADS), 0, st, d); return; }
+    }
     if (variant == 1 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2>), grid, dim3(NTHREADS), 0, st, d);
     else if (variant == 2 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);
     else if (variant == 3 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d);
