@@ -1,0 +1,123 @@
+"""GPU coverage of the remaining BASELINE.json configs and of the CLI:
+ configs[2]  Band-MoE stress (num_experts=8, full-size T=752) vs the oracle, routing bit-exact;
+ configs[4]  long-form: chunked latent sampling + overlap-add vocoder (build-defined);
+ configs[0]/harness  scripts/test_final.py end to end on synthetic items."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from tests.helpers import SEED, clip_batch, describe, exp_noise, gumbel_arrays, rel_l2
+from versband_amd import longform
+from versband_amd import model as vm
+from versband_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from versband_amd.engine import Context
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return Context("cuda:0")
+
+
+def test_c3_moe_stress_e8_full_size_vs_oracle(ctx):
+    """num_experts = 8 (band = 96 channels: K tail of the band GEMMs, 16 routed groups), T = 752, L = 80."""
+    from versband_amd.engine import DiTEngine
+    cfg = synth.DiTConfig(num_experts=8)
+    sd = synth.make_state_dict(synth.dit_shapes(cfg), SEED)
+    eng = DiTEngine(ctx, cfg, sd, precision="split")
+    B, T, Lc, E = 2, 752, 80, 8
+    inp = clip_batch(B, T, Lc)
+    noise = [exp_noise(B, T, E, br, 4) for br in (0, 1)]
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2 * B,), 583, dtype=torch.long)
+    v, routes = eng.forward(inp["x_latent"], t_idx, cond, noise=gumbel_arrays(noise), return_routes=True)
+    torch.cuda.synchronize()
+    N = B * T
+    for br, key in ((0, "t5_cond"), (1, "t5_uncond")):
+        c = ref_cpu.dit_precompute(sd, inp[key], inp["midi"], inp["beats"], T)
+        ref, aux = ref_cpu.dit_forward(sd, inp["x_latent"], t_idx[:B], c, noise[br], return_aux=True)
+        assert rel_l2(v[br * B:(br + 1) * B], ref) < 1e-4, describe(f"E=8 forward branch {br}", v[br * B:(br + 1) * B], ref)
+        for i in range(4):
+            got_c = routes[i, 0, br * N:(br + 1) * N].cpu().long()
+            got_a = routes[i, 1, br * N:(br + 1) * N].cpu().long()
+            # bit-exact on identical noise, except where the two best gate values differ by less than the fp32-class
+            # error of the logits (reported, must be a vanishing fraction)
+            bad = int((got_c != aux[f"ic{i}"]).sum()) + int((got_a != aux[f"ia{i}"]).sum())
+            assert bad <= 2, f"block {i}: {bad} of {2 * N} routing decisions differ"
+        hist = torch.bincount(routes[0, 0].cpu().long(), minlength=E)
+        assert (hist > 0).all(), f"degenerate routing {hist.tolist()}"
+
+
+def test_c5_longform_chunked_sampling(ctx):
+    from versband_amd.engine import DiTEngine
+    cfg = synth.DiTConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(cfg), SEED)
+    eng = DiTEngine(ctx, cfg, sd, precision="bf16")
+    B, T, Lc, win, ov = 2, 80, 8, 48, 16
+    inp = clip_batch(B, T, Lc)
+    idx, dts = vm.euler_tables(4)
+    z = longform.sample_long(eng, inp["x_latent"], inp["t5_cond"], inp["t5_uncond"], inp["midi"], inp["beats"], idx, dts, 3.0,
+                             window=win, overlap=ov, seed=3, clip_base=0)
+    torch.cuda.synchronize()
+    assert z.shape == (B, 20, T) and torch.isfinite(z).all()
+    plan = longform.plan_windows(T, win, ov)
+    # window 0 sampled on its own (same clip keys) reproduces the chunked result outside the overlap
+    s0, n0 = plan[0]
+    cond0 = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"][..., 2 * s0:2 * (s0 + n0)],
+                                inp["beats"][..., 2 * s0:2 * (s0 + n0)], n0)
+    z0 = eng.sample_cfg(inp["x_latent"][:, :, s0:s0 + n0], cond0, idx, dts, 3.0, seed=3, clip_base=0)
+    torch.cuda.synchronize()
+    keep = plan[1][0]
+    assert torch.equal(z[:, :, :keep].cpu(), z0[:, :, :keep].cpu()), describe("window interior", z[:, :, :keep], z0[:, :, :keep])
+    # a clip that fits one window goes through untouched
+    zs = longform.sample_long(eng, inp["x_latent"][:, :, :40], inp["t5_cond"], inp["t5_uncond"], inp["midi"][..., :80],
+                              inp["beats"][..., :80], idx, dts, 3.0, window=win, overlap=ov, seed=3)
+    cond1 = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"][..., :80], inp["beats"][..., :80], 40)
+    z1 = eng.sample_cfg(inp["x_latent"][:, :, :40], cond1, idx, dts, 3.0, seed=3)
+    torch.cuda.synchronize()
+    assert torch.equal(zs.cpu(), z1.cpu())
+    # past max_len the plain path refuses loudly instead of reading beyond the RoPE table
+    from versband_amd._lib import VersbandError
+    big = clip_batch(1, 1504, Lc)
+    cb = eng.precompute_cond(torch.cat([big["t5_cond"], big["t5_uncond"]]), big["midi"], big["beats"], 1504)
+    with pytest.raises(VersbandError):
+        eng.sample_cfg(big["x_latent"], cb, idx, dts, 3.0)
+
+
+def test_c5_overlap_add_vocoder_equals_whole_clip(ctx):
+    from versband_amd.engine import build_hifigan
+    hcfg = synth.HifiGanConfig()
+    sdh = synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2)
+    net = build_hifigan(ctx, sdh, hcfg.as_hparams())
+    mel = torch.from_numpy(synth.prng.uniform(9, 2 * 80 * 700, -5.0, 1.5).reshape(2, 80, 700)).cuda()
+    whole = net.run(mel)
+    chunked = longform.vocode_chunked(net, mel, chunk=256, halo=32)
+    torch.cuda.synchronize()
+    assert chunked.shape == whole.shape
+    assert float((chunked - whole).abs().max()) < 2e-6, describe("chunked vs whole vocoding", chunked, whole)
+
+
+def test_cli_synthetic_end_to_end(tmp_path):
+    out = tmp_path / "gen"
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "test_final.py"), "--synthetic", "2", "--synthetic_frames", "150",
+           "--ddim_steps", "3", "--scales", "3", "--n_samples", "2", "--save_dir", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = out / "cond_gtcodec_accomp_scale_3.0"
+    wavs = sorted(os.listdir(d))
+    assert wavs == ["0-0000[0][accomp].wav", "0-0000[1][accomp].wav", "0-0001[0][accomp].wav", "0-0001[1][accomp].wav"]
+    import wave
+    with wave.open(str(d / wavs[0])) as f:
+        assert f.getframerate() == 24000 and f.getsampwidth() == 2 and f.getnframes() == 152 * 320
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2").astype(np.float64) / 32767.0
+    rms_db = 20 * np.log10(np.sqrt(np.mean(pcm ** 2)))
+    assert abs(rms_db + 23.0) < 0.5                      # normalize_loudness(-23 dB RMS), scripts/test_final.py:342-347
+    assert (out / "clap.csv").exists()

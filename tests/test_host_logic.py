@@ -138,3 +138,22 @@ def test_synthetic_inputs_respect_embedding_ranges():
     assert int(c["midi"][0, -1]) == 128 and int(c["beats"][0, -1]) == 2               # pad values
     a, b = synth.make_clip_inputs(1234, 3, 16), synth.make_clip_inputs(1234, 4, 16)
     assert not torch.equal(a["x_latent"], b["x_latent"])
+
+
+def test_longform_window_plan_and_crossfade_partition_of_unity():
+    from versband_amd import longform
+    assert longform.plan_windows(700, 1500, 128) == [(0, 700)]
+    plan = longform.plan_windows(4500, 1500, 128)
+    assert plan[0] == (0, 1500) and plan[-1][0] + plan[-1][1] == 4500 and all(n == 1500 for _, n in plan)
+    covered = torch.zeros(4500)
+    for s, n in plan:
+        covered[s:s + n] += 1
+    assert covered.min() >= 1
+    # cross-fading constant windows gives back the constant (weights sum to one everywhere)
+    parts = [torch.full((2, 3, n), 7.0) for _, n in plan]
+    out = longform.crossfade_windows(parts, plan, 4500)
+    assert torch.allclose(out, torch.full((2, 3, 4500), 7.0), atol=1e-6)
+    # a window's interior (outside every overlap) is passed through untouched
+    parts = [torch.full((1, 1, n), float(i)) for i, (_, n) in enumerate(plan)]
+    out = longform.crossfade_windows(parts, plan, 4500)
+    assert float(out[0, 0, 200]) == 0.0 and float(out[0, 0, plan[1][0] + 700]) == 1.0
