@@ -29,7 +29,9 @@ for Ci, Co, T, k, dil, res, act in cases:
     line = f"Ci={Ci:4d} Co={Co:4d} T={T:6d} k={k:2d} d={dil}:"
     flops = 2.0 * B * Co * Ci * k * T
     byts = 4.0 * B * T * (Ci + Co * (2 if res else 1))
-    for split in (False, True):
+    for split, cfgv in ((False, 0), (True, 0), (True, 1)):
+        os.environ['VB_CONV_CFG'] = str(cfgv)
+
         def run():
             L.check(lib.vb_conv1d_f32(L.ptr(x), L.ptr(wp), L.ptr(b), B, Ci, T, Co, k, dil, pad, 1, 0, 0, T, act, 0.1,
                                       L.ptr(r) if res else None, L.ptr(out), L.ptr(wx3) if split else None, cip, L.stream_ptr()), "conv")
@@ -44,5 +46,5 @@ for Ci, Co, T, k, dil, res, act in cases:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
-        line += f"  {'x3 ' if split else 'f32'} {us:8.1f}us {flops / us / 1e6:7.1f}TF {byts / us / 1e6:6.2f}TB/s"
+        line += f"  {('x3c%d' % cfgv) if split else 'f32 '} {us:8.1f}us {flops / us / 1e6:7.1f}TF {byts / us / 1e6:6.2f}TB/s"
     print(line, flush=True)

@@ -13,6 +13,8 @@
 // V^T (stored d-major by the QKV GEMM epilogue) with two 8-byte LDS reads - no
 // cross-lane shuffle of P at all.
 // SPLIT = bf16x3 parity mode (hi*hi + lo*hi + hi*lo for both Q K^T and P V).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define HD 96
@@ -33,7 +35,8 @@ struct AttnDev {
     float scale_log2e;
 };
 
-template <bool SPLIT>
+// ABL (tuning only): 1 = no K/V tile traffic in the loop, 2 = no softmax math, 3 = no P.V MFMAs, 4 = no Q.K^T MFMAs
+template <bool SPLIT, int ABL = 0>
 __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
     constexpr int NP = SPLIT ? 2 : 1;
     __shared__ __attribute__((aligned(16))) bf16_t Kl[NP][KT * KPITCH];
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
             const int key0 = kt * KT;
             __syncthreads();
             if constexpr (!SPLIT) {
-                tile_store(kreg, vreg, 0);
+                if (ABL != 1 || kt == 0) tile_store(kreg, vreg, 0);
             } else {
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) {
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
             }
             __syncthreads();
             if constexpr (!SPLIT) {
-                if (kt + 1 < ntiles) tile_load(kt + 1, kreg, vreg, 0);
+                if (ABL != 1 && kt + 1 < ntiles) tile_load(kt + 1, kreg, vreg, 0);
             }
             // ---- S^T = K Q^T  (two 32-key sub-tiles)
             f32x16 s[2];
@@ -129,7 +132,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 for (int ks = 0; ks < 6; ++ks) {
                     const int off = (kb * 32 + ql) * KPITCH + ks * 16 + g * 8;
                     bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Kl[0][off]);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                    if constexpr (ABL == 4) s[kb][ks] += (float)kf[0];
+                    else s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
                     if constexpr (SPLIT) {
                         bf16x8 klo = *reinterpret_cast<const bf16x8*>(&Kl[1][off]);
                         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qf[ks], s[kb], 0, 0, 0);
@@ -137,36 +141,47 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                     }
                 }
             }
-            // ---- online softmax (base-2 domain)
-            float tmax = -1e30f;
+            if constexpr (ABL != 2) {
+            // ---- online softmax (base-2 domain).  Lean VALU path: the key mask is applied only on a partial tile,
+            // the scale is folded into one fma per element feeding the raw v_exp_f32, and the accumulator rescale is
+            // skipped (wave-uniformly) on tiles that do not raise any row maximum.
+            const bool partial = key0 + KT > nkeys;
+            if (partial) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        if (key >= nkeys) s[kb][r] = -INFINITY;
+                    }
+            }
+            float tmax = s[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    float v = (key < nkeys) ? s[kb][r] * p.scale_log2e : -1e30f;
-                    s[kb][r] = v;
-                    tmax = fmaxf(tmax, v);
-                }
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
+            const float m_new = fmaxf(m_run, tmax * p.scale_log2e);     // every tile holds >= 1 valid key: finite
+            if (!__all(m_new == m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float e = exp2f(s[kb][r] - m_new);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -m_run));    // exp2(-inf) = 0 for masked keys
                     s[kb][r] = e;
                     psum += e;
                 }
             l_run += psum;
+            }
             // ---- O^T += V^T P^T   (k-slot e of lane group g <-> key base + 8*(e>>2) + 4g + (e&3))
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -186,7 +201,8 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                         bf16x4 v0 = *reinterpret_cast<const bf16x4*>(&Vl[0][voff]);
                         bf16x4 v1 = *reinterpret_cast<const bf16x4*>(&Vl[0][voff + 8]);
                         bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, acc[dt], 0, 0, 0);
+                        if constexpr (ABL == 3) acc[dt][0] += (float)vf[0] * (float)ph[0];
+                        else acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ph, acc[dt], 0, 0, 0);
                         if constexpr (SPLIT) {
                             bf16x4 w0 = *reinterpret_cast<const bf16x4*>(&Vl[1][voff]);
                             bf16x4 w1 = *reinterpret_cast<const bf16x4*>(&Vl[1][voff + 8]);
@@ -262,8 +278,16 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     ProfScope prof(1, 4.0 * a.B * a.H * a.T * a.hd * ((a.has_self ? a.T : 0) + (a.has_cross ? a.L : 0)), st);
     d.nq = cdiv(a.T, 128);
     dim3 grid(d.nq * ((a.B * a.H + 7) / 8 * 8));
-    if (a.q.np == 2) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, d);
+    if (a.q.np == 2) hipLaunchKernelGGL((attn_kernel<true, 0>), grid, dim3(256), 0, st, d);
+    else {
+        const char* ea = getenv("VB_ATTN_ABLATE");
+        const int abl = ea ? atoi(ea) : 0;
+        if (abl == 1) hipLaunchKernelGGL((attn_kernel<false, 1>), grid, dim3(256), 0, st, d);
+        else if (abl == 2) hipLaunchKernelGGL((attn_kernel<false, 2>), grid, dim3(256), 0, st, d);
+        else if (abl == 3) hipLaunchKernelGGL((attn_kernel<false, 3>), grid, dim3(256), 0, st, d);
+        else if (abl == 4) hipLaunchKernelGGL((attn_kernel<false, 4>), grid, dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((attn_kernel<false, 0>), grid, dim3(256), 0, st, d);
+    }
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

@@ -15,6 +15,8 @@
 //    (grid.z = batch x phase), each with ceil(k/stride) taps.
 //  * per-batch "weights" (w_bstride) let the VAE's single-head attention (q^T k and P v)
 //    run on the same kernel.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define CK 16
@@ -446,7 +448,11 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * (a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize), st);
     if (a.wp && !a.w_bstride) {
         if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
+        // VB_CONV_CFG (tuning knob): 1 = wide-T tile (64co x 256t) for 32 < Co <= 64
+        const char* ev = getenv("VB_CONV_CFG");
+        const int cfgv = ev ? atoi(ev) : 0;
         if (a.Co > 64) launch_cfg_x3<2, 2, 2, 2>(d, n_count, a.B, st);
+        else if (a.Co > 32 && cfgv == 1) launch_cfg_x3<2, 2, 1, 4>(d, n_count, a.B, st);
         else if (a.Co > 32) launch_cfg_x3<2, 2, 1, 2>(d, n_count, a.B, st);
         else launch_cfg_x3<1, 4, 1, 2>(d, n_count, a.B, st);
     } else if (a.Co > 64) launch_cfg<2, 2, 2, 2>(d, n_count, a.B, st);
