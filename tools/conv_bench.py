@@ -14,7 +14,7 @@ cases = [  # Ci, Co, T, k, dil, res, act
     (1536, 1536, 752, 3, 1, True, 0), (768, 768, 1504, 3, 1, True, 0), (384, 384, 1504, 3, 1, True, 0), (384, 80, 1504, 5, 1, False, 0),
     (256, 256, 12032, 3, 1, True, 1), (256, 256, 12032, 11, 5, True, 1), (128, 128, 60160, 7, 3, True, 1),
     (64, 64, 240640, 3, 1, True, 1), (64, 64, 240640, 11, 5, True, 1), (32, 32, 481280, 3, 1, True, 1), (32, 32, 481280, 7, 3, True, 1),
-    (32, 32, 481280, 11, 5, True, 1), (32, 1, 481280, 7, 1, False, 1), (20, 768, 752, 5, 1, False, 0),
+    (32, 1, 481280, 7, 1, False, 1), (20, 768, 752, 5, 1, False, 0),
 ]
 torch.manual_seed(0)
 for Ci, Co, T, k, dil, res, act in cases:
@@ -29,8 +29,8 @@ for Ci, Co, T, k, dil, res, act in cases:
     line = f"Ci={Ci:4d} Co={Co:4d} T={T:6d} k={k:2d} d={dil}:"
     flops = 2.0 * B * Co * Ci * k * T
     byts = 4.0 * B * T * (Ci + Co * (2 if res else 1))
-    for split, cfgv in ((False, 0), (True, 0), (True, 1)):
-        os.environ['VB_CONV_CFG'] = str(cfgv)
+    for split, cfgv in ((False, 0), (True, 0), (True, 1), (True, 2), (True, 3), (True, 4)):
+        os.environ['VB_CONV_ABLATE'] = str(cfgv)
 
         def run():
             L.check(lib.vb_conv1d_f32(L.ptr(x), L.ptr(wp), L.ptr(b), B, Ci, T, Co, k, dil, pad, 1, 0, 0, T, act, 0.1,
@@ -46,5 +46,6 @@ for Ci, Co, T, k, dil, res, act in cases:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
-        line += f"  {('x3c%d' % cfgv) if split else 'f32 '} {us:8.1f}us {flops / us / 1e6:7.1f}TF {byts / us / 1e6:6.2f}TB/s"
+        line += (f"  f32 {us:7.1f}us" if not split else (f"  x3 {us:7.1f}us {flops / us / 1e6:6.1f}TF" if cfgv == 0 else
+                 f"  {['', 'noX', 'noW', 'noMFMA', 'noEpi'][cfgv]} {us:7.1f}"))
     print(line, flush=True)

@@ -54,15 +54,40 @@ __device__ __forceinline__ void store1p(bf16_t* base, int64_t plane, int np, int
     if (np == 2) base[plane + idx] = f2bf(v - bf2f(hi));
 }
 
+// Epilogue in two halves.  epi_load<EPI>() issues every global LOAD an output quad needs (bias, residual + gate,
+// RoPE table entries, partial expert sum); epi_store<EPI>() does the math and the stores.  The kernels call epi_load
+// for all quads of a 32-row slab first and only then epi_store: vmcnt retires loads and stores in order, so a load
+// issued behind a store also waits for that store's round trip - interleaved they serialise one memory round trip per
+// quad (measured 1.4x on the residual GEMMs).
+struct EpiPre { float4 a, b; };
+
 template <int EPI>
-__device__ __forceinline__ void epilogue4(const GemmDev& p, int g, int m, int n, float v[4]) {
+__device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok, int n, EpiPre& e) {
+    e.a = make_float4(0.f, 0.f, 0.f, 0.f); e.b = e.a;
+    if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T) {
+        if (p.bias) e.a = *reinterpret_cast<const float4*>(p.bias + g * p.bias_group_stride + n);
+    } else if constexpr (EPI == EPI_RESID_GATE) {
+        const int col = g * p.c_noff_group + n;
+        e.a = *reinterpret_cast<const float4*>(p.out32 + (int64_t)m * p.ldc32 + col);
+        e.b = *reinterpret_cast<const float4*>(p.gate + (int64_t)(m / p.T) * p.gate_ld + col);
+    } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
+        e.a = *reinterpret_cast<const float4*>(p.y32_in + (int64_t)tok * p.ldc32 + n);
+    } else if constexpr (EPI == EPI_QKV_ROPE) {
+        if (n < 2 * p.D) {
+            const int nn = n % p.D, t = m % p.T;
+            const int jd = (nn % p.hd) >> 1;
+            const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (int64_t)t * (p.hd / 2) + jd);
+            const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (int64_t)t * (p.hd / 2) + jd);
+            e.a = make_float4(cs.x, cs.y, sn.x, sn.y);
+        }
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int tok, float scale, int n, float v[4], const EpiPre& e) {
     // m: global row (slot) index, n: column within the group's [0,N), 4 consecutive columns, all < N
     if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T) {
-        if (p.bias) {
-            const float* b = p.bias + g * p.bias_group_stride + n;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += b[i];
-        }
+        v[0] += e.a.x; v[1] += e.a.y; v[2] += e.a.z; v[3] += e.a.w;
     }
     if constexpr (EPI == EPI_PLANES) {
         store4p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + n, v);
@@ -73,12 +98,10 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int g, int m, int n,
     } else if constexpr (EPI == EPI_F32) {
         *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_RESID_GATE) {
-        int col = g * p.c_noff_group + n;
-        float4* dst = reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + col);
-        const float4 gt = *reinterpret_cast<const float4*>(p.gate + (int64_t)(m / p.T) * p.gate_ld + col);
-        float4 h = *dst;
-        h.x += gt.x * v[0]; h.y += gt.y * v[1]; h.z += gt.z * v[2]; h.w += gt.w * v[3];
-        *dst = h;
+        const int col = g * p.c_noff_group + n;
+        float4 h = e.a;
+        h.x += e.b.x * v[0]; h.y += e.b.y * v[1]; h.z += e.b.z * v[2]; h.w += e.b.w * v[3];
+        *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + col) = h;
     } else if constexpr (EPI == EPI_SWIGLU) {
         float o0 = silu_f(v[0]) * v[1], o1 = silu_f(v[2]) * v[3];
         int64_t idx = (int64_t)m * p.ldc + g * p.c_noff_group + (n >> 1);
@@ -91,14 +114,9 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int g, int m, int n,
             *reinterpret_cast<bf16x2*>(p.out + p.out_plane + idx) = lv;
         }
     } else if constexpr (EPI == EPI_SCATTER_F32) {
-        int tok = p.rows_out[m];
-        float s = p.row_scale[tok];
-        *reinterpret_cast<float4*>(p.out32 + (int64_t)tok * p.ldc32 + n) = make_float4(s * v[0], s * v[1], s * v[2], s * v[3]);
+        *reinterpret_cast<float4*>(p.out32 + (int64_t)tok * p.ldc32 + n) = make_float4(scale * v[0], scale * v[1], scale * v[2], scale * v[3]);
     } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
-        int tok = p.rows_out[m];
-        float s = p.row_scale[tok];
-        const float4 y = *reinterpret_cast<const float4*>(p.y32_in + (int64_t)tok * p.ldc32 + n);
-        float o[4] = {y.x + s * v[0], y.y + s * v[1], y.z + s * v[2], y.w + s * v[3]};
+        float o[4] = {e.a.x + scale * v[0], e.a.y + scale * v[1], e.a.z + scale * v[2], e.a.w + scale * v[3]};
         store4p(p.out, p.out_plane, p.out_np, (int64_t)tok * p.ldc + n, o);
     } else if constexpr (EPI == EPI_HEADS_T) {
         int b = m / p.T, t = m - b * p.T;
@@ -113,10 +131,7 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int g, int m, int n,
         int nn = n - sec * p.D;
         int b = m / p.T, t = m - b * p.T;
         if (sec < 2) {
-            int jd = (nn % p.hd) >> 1;   // rotary pair index inside the head
-            const float* cs = p.rope_cos + (int64_t)t * (p.hd / 2) + jd;
-            const float* sn = p.rope_sin + (int64_t)t * (p.hd / 2) + jd;
-            float c0 = cs[0], c1 = cs[1], s0 = sn[0], s1 = sn[1];
+            const float c0 = e.a.x, c1 = e.a.y, s0 = e.a.z, s1 = e.a.w;
             float o[4] = {v[0] * c0 - v[1] * s0, v[0] * s0 + v[1] * c0, v[2] * c1 - v[3] * s1, v[2] * s1 + v[3] * c1};
             if (sec == 0) store4p(p.q, p.q_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
             else store4p(p.k, p.k_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
@@ -128,6 +143,39 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int g, int m, int n,
                 store1p(p.vt, p.vt_plane, p.qkv_np, ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t, v[i]);
             }
         }
+    }
+}
+
+// the whole epilogue of one wave: rows slab by slab (i), loads of a slab first, then math + stores
+template <int EPI>
+__device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&acc)[2][2], int row_base, int rows_end, int n_base,
+                                              int frow, int fk) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = row_base + i * 32 + frow;
+        if (slot >= rows_end) continue;
+        int tok = slot; float scale = 1.f;
+        if constexpr (EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES) {
+            tok = p.rows_out[slot];
+            scale = p.row_scale[tok];
+        }
+        EpiPre pre[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_base + j * 32 + q * 8 + fk * 4;
+                if (n < p.N) epi_load<EPI>(p, g, slot, tok, n, pre[j][q]);
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_base + j * 32 + q * 8 + fk * 4;
+                if (n >= p.N) continue;     // N % 4 == 0 is required
+                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                epi_store<EPI>(p, g, slot, tok, scale, n, v, pre[j][q]);
+            }
     }
 }
 
@@ -244,24 +292,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_kernel(const GemmDev p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns row m = ..+(lane&31); 4 consecutive n per accumulator quad
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int slot = row0 + wr * 64 + i * 32 + frow;
-        if (slot >= rows_end) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
-                if (n >= p.N) continue;     // N % 4 == 0 is required
-                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                epilogue4<EPI>(p, g, slot, n, v);
-            }
-        }
-    }
+    wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
 }
-
 
 // ---- variant 2: tiles DMA'd straight into an LDS ring (global_load_lds, 16 B / lane, no VGPR staging, no ds_write) ----
 // The LDS image must be lane-linear (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane
@@ -406,24 +438,15 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         }
     }
 
+    if constexpr (ABL == 4) {
+        float sink = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int slot = row0 + wr * 64 + i * 32 + frow;
-        if (slot >= rows_end) continue;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
-                if (n >= p.N) continue;
-                float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                if constexpr (ABL == 4) {
-                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));     // keep the accumulators alive, store nothing
-                } else {
-                    epilogue4<EPI>(p, g, slot, n, v);
-                }
-            }
-        }
+            for (int j = 0; j < 2; ++j) sink += acc[i][j][0] + acc[i][j][9];
+        if (sink == 12345.678f) p.out32[0] = sink;
+    } else {
+        wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
     }
 }
 
