@@ -199,10 +199,7 @@ class NetBuilder:
              in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
              acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32):
         w_x3, ci_pad = None, 0
-        # layers with <= 32 channels are bound by data movement, where the leaner exact-f32 kernel is faster
-        # (tools/conv_bench.py); everything wider runs the bf16x3 MFMA kernel
-        narrow = Ci <= 32 and 1 < Co <= 32
-        if self.precision == "split" and w is not None and w_buf == -1 and not out_transposed and not narrow:
+        if self.precision == "split" and w is not None and w_buf == -1 and not out_transposed:
             planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
             self.keep.append(planes)
             w_x3 = planes.data_ptr()
