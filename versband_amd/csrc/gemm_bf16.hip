@@ -355,7 +355,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         }
     }
     const int n0 = tile_n * BN;
-    const bool vt_tile = (EPI == EPI_QKV_ROPE) && (n0 >= 2 * p.D);       // block-uniform (2D is a multiple of BN)
     const int KT = (ABL == 5) ? 0 : p.K / BKT;
     const int total = KT * p.nseg;
 
@@ -432,10 +431,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
                     if constexpr (ABL == 2) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[i][j][e] += (float)af[i][e] * (float)bf[j][e];
-                    } else if (EPI == EPI_QKV_ROPE && vt_tile) {
-                        // V columns: un-swapped operands -> a lane owns one head channel d and 4 consecutive tokens,
-                        // so V^T[d][t..t+3] is one 8-byte store instead of four scattered 2-byte stores
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
                     } else {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
                     }
@@ -450,32 +445,6 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
 #pragma unroll
             for (int j = 0; j < 2; ++j) sink += acc[i][j][0] + acc[i][j][9];
         if (sink == 12345.678f) p.out32[0] = sink;
-    } else if (EPI == EPI_QKV_ROPE && vt_tile) {
-        // transposed accumulators: lane -> column n (= head channel), quad -> 4 consecutive rows m (= tokens)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wc * 64 + j * 32 + frow;
-            if (n >= p.N) continue;
-            const int c = n - 2 * p.D;
-            const int hh = c / p.hd, d = c - hh * p.hd;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m = row0 + wr * 64 + i * 32 + q * 8 + fk * 4;
-                    if (m >= rows_end) continue;
-                    const int b = m / p.T, t = m - b * p.T;
-                    float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                    if ((p.T & 3) == 0 && m + 3 < rows_end) {      // 4 | T: the quad is 8-byte aligned and inside one batch item
-                        store4p(p.vt, p.vt_plane, p.qkv_np, ((int64_t)(b * p.H + hh) * p.hd + d) * p.Tpad + t, v);
-                    } else {
-                        for (int e = 0; e < 4 && m + e < rows_end; ++e) {
-                            const int be = (m + e) / p.T, te = (m + e) - be * p.T;
-                            store1p(p.vt, p.vt_plane, p.qkv_np, ((int64_t)(be * p.H + hh) * p.hd + d) * p.Tpad + te, v[e]);
-                        }
-                    }
-                }
-        }
     } else {
         wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
     }
@@ -507,7 +476,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return VB_OK;
     if (a.N % 4 || a.K % 8 || a.lda % 8 || a.ldb % 8) VB_FAIL(VB_E_INVALID, "gemm: N%%4, K%%8, lda%%8, ldb%%8 must be 0 (N=%d K=%d)", a.N, a.K);
     if (a.nseg != 1 && a.nseg != 3) VB_FAIL(VB_E_INVALID, "gemm: nseg must be 1 or 3");
-    if (a.epi == EPI_QKV_ROPE && ((2 * a.D) % BN || a.Tpad % 4)) VB_FAIL(VB_E_INVALID, "gemm: QKV epilogue needs 2D %% %d == 0 (D=%d)", BN, a.D);
     GemmDev d;
     d.A = a.A; d.a_plane = a.a_plane; d.lda = a.lda; d.a_rows = a.a_rows; d.a_koff_group = a.a_koff_group;
     d.B = a.B; d.b_plane = a.b_plane; d.ldb = a.ldb; d.b_group_stride = a.b_group_stride;
