@@ -292,7 +292,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16 DiT (fp32 accumulate) + fp32 VAE/vocoder" if args.precision == "bf16" else "bf16x3 split DiT + fp32 VAE/vocoder",
+            "dtype": ("bf16 DiT (fp32 accumulate)" if args.precision == "bf16" else "bf16x3 split DiT") +
+                     " + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32",
             "data": "synthetic (seeded PRNG clips, random-init checkpoints of the configured architecture)",
             "config": {"workload": f"{B} x 20 s clips per GPU (T_lat=752, T_mel=1504, 24 kHz), {args.flow_steps} Euler steps x 2 NFE (CFG "
                                    f"scale {args.scale}), Band-MoE E=4, VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml",
