@@ -30,7 +30,7 @@ T_LAT, L_CTX = 752, 80
 SEED = 1234
 PEAK = {0: ("mfma", 2500.0, "bf16 MFMA GEMM (DiT projections + experts)"),
         1: ("mfma", 2500.0, "bf16 flash attention"),
-        2: ("mfma", 157.3, "fp32 MFMA implicit-GEMM conv1d (VAE + HiFi-GAN)")}
+        2: ("mfma", 2500.0 / 3.0, "split-bf16 (bf16x3) MFMA implicit-GEMM conv1d (VAE + HiFi-GAN); peak = bf16 dense / 3 passes")}
 
 
 _T0 = time.time()
