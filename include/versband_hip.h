@@ -180,7 +180,9 @@ int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, cons
                         int T, float eps, void* out_planes, int np, void* stream);
 /* first argmax of logits + gumbel (hard Gumbel-softmax, vocal2music_moe.py:81-93) */
 int vb_router_top1(const float* logits, const float* gumbel, int N, int E, int32_t* idx, void* stream);
-/* stable bucketing of tokens by (caption, acoustic) expert: group_off int32[2E+1], perm int32[2N] */
+/* stable bucketing of tokens by (caption, acoustic) expert: group_off int32[2E+1]; perm int32[2N + scratch] where the
+ * first 2N entries are the slot -> token permutation and scratch = vb_route_bucket_scratch_ints(N, E) */
+int vb_route_bucket_scratch_ints(int N, int E);
 int vb_route_bucket(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, void* stream);
 /* generic GEMM  C[M][N] f32 = A[M][K] planes x B[N][K]^T planes (+bias) */
 int vb_gemm_bf16(const void* A, const void* Bw, const float* bias, int M, int N, int K, int np, float* C, void* stream);

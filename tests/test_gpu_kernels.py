@@ -185,10 +185,10 @@ def test_route_bucket(lib, N, E):
     if N > 100:
         ic[ic == 2] = 1                                # an empty group
     off = torch.full((2 * E + 1,), -1, dtype=torch.int32, device="cuda")
-    perm = torch.full((2 * N,), -1, dtype=torch.int32, device="cuda")
+    perm = torch.full((2 * N + lib.vb_route_bucket_scratch_ints(N, E),), -1, dtype=torch.int32, device="cuda")
     L.check(lib.vb_route_bucket(L.ptr(dev(ic)), L.ptr(dev(ia)), N, E, L.ptr(off), L.ptr(perm), L.stream_ptr()), "bucket")
     sync()
-    off, perm = off.cpu(), perm.cpu()
+    off, perm = off.cpu(), perm.cpu()[:2 * N]
     cnt = torch.cat([torch.bincount(ic.long(), minlength=E), torch.bincount(ia.long(), minlength=E)])
     assert torch.equal(off, torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]).int())
     for g in range(2 * E):
@@ -206,7 +206,7 @@ def test_grouped_swiglu(lib, npl):
     idx = torch.from_numpy(prng.randint(5, N, 0, G)).int()
     scale = rnd((N,), "ss").abs() + 0.1
     off = torch.zeros(2 * G + 1, dtype=torch.int32, device="cuda")
-    perm = torch.zeros(2 * N, dtype=torch.int32, device="cuda")
+    perm = torch.zeros(2 * N + lib.vb_route_bucket_scratch_ints(N, G), dtype=torch.int32, device="cuda")
     L.check(lib.vb_route_bucket(L.ptr(dev(idx)), L.ptr(dev(idx)), N, G, L.ptr(off), L.ptr(perm), L.stream_ptr()), "bucket")
     w13 = torch.stack([w1, w3], dim=2).reshape(G, 2 * H, D)
     up, w13p, w2p = dev(pack.to_planes(u, npl)), dev(pack.to_planes(w13, npl)), dev(pack.to_planes(w2, npl))

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "vb_hifigan_forward": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_rmsnorm_modulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, P]),
     "vb_router_top1": (c_int, [P, P, c_int, c_int, P, P]),
+    "vb_route_bucket_scratch_ints": (c_int, [c_int, c_int]),
     "vb_route_bucket": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_gemm_bf16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "vb_grouped_swiglu": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P, P]),

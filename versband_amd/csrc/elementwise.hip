@@ -271,6 +271,39 @@ int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n
     return VB_OK;
 }
 
+// Sum EE per-lane partials over the wave with a halving butterfly: exchanging with lane^32 a lane keeps half of the
+// values, with lane^16 a quarter, ...; the last value is then summed over the remaining lane bits.  Returns, on lane e,
+// the full sum of value e (EE + log2(64/EE) - 1 shuffles instead of 6*EE).
+template <int EE>
+__device__ __forceinline__ float reduce_logits(const float (&part)[16], int lane) {
+    float v[EE];
+#pragma unroll
+    for (int e = 0; e < EE; ++e) v[e] = part[e];
+    int off = 32;
+#pragma unroll
+    for (int width = EE; width > 1; width >>= 1) {
+        const int half = width >> 1;
+        const bool upper = (lane & off) != 0;
+#pragma unroll
+        for (int j = 0; j < half; ++j) {
+            const float send = upper ? v[j] : v[j + half];
+            const float keep = upper ? v[j + half] : v[j];
+            v[j] = keep + __shfl_xor(send, off, 64);
+        }
+        off >>= 1;
+    }
+    float r = v[0];
+    for (; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+    // value e sits on the lanes whose top log2(EE) bits spell e (bit 5 = most significant): fetch it to lane e
+    int src = 0;
+#pragma unroll
+    for (int bit = 0, o = 32, w = EE; w > 1; w >>= 1, o >>= 1, ++bit) {
+        const int nb = (EE == 4) ? 2 : 3;
+        if ((lane >> (nb - 1 - bit)) & 1) src += o;
+    }
+    return __shfl(r, src, 64);
+}
+
 // ---------------------------------------------------------------------------
 // Band-MoE router (vocal2music_moe.py:132-151): one wave per token.
 //   lc = cq . Wg^T + bg ; ic = argmax(lc + G2) ; ia = argmax(la + G3) (first maximum wins, like
@@ -318,18 +351,40 @@ __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __r
             for (int j = 0; j < 4; ++j) xv[i * 4 + j] = 0.f;
         }
     }
-    float best = -INFINITY; int bi = 0;
-    for (int e = 0; e < E; ++e) {
-        float acc = 0.f;
+    // E partial dot products per lane, reduced together: after exchanging with lane^32 a lane keeps half of the
+    // experts, after lane^16 a quarter, ... then the remaining value is summed over the rest of the wave
+    // (7 shuffles for E = 4 instead of 24); lane e then holds logit e.
+    float part[16];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int k = lane * 4 + i * 256;
-            if (k < D) {
-                const float4 wv = *reinterpret_cast<const float4*>(Wg + (int64_t)e * D + k);
-                acc += xv[i * 4] * wv.x + xv[i * 4 + 1] * wv.y + xv[i * 4 + 2] * wv.z + xv[i * 4 + 3] * wv.w;
+    for (int e = 0; e < 16; ++e) {
+        float acc = 0.f;
+        if (e < E) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int k = lane * 4 + i * 256;
+                if (k < D) {
+                    const float4 wv = *reinterpret_cast<const float4*>(Wg + (int64_t)e * D + k);
+                    acc += xv[i * 4] * wv.x + xv[i * 4 + 1] * wv.y + xv[i * 4 + 2] * wv.z + xv[i * 4 + 3] * wv.w;
+                }
             }
         }
-        acc = wave_sum(acc) + bg[e];
+        part[e] = acc;
+    }
+    float logit_e = 0.f;      // valid on lanes [0,E)
+    if (E == 4) logit_e = reduce_logits<4>(part, lane);
+    else if (E == 8) logit_e = reduce_logits<8>(part, lane);
+    else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < E) {
+                const float r = wave_sum(part[e]);
+                if (lane == e) logit_e = r;
+            }
+        }
+    }
+    float best = -INFINITY; int bi = 0;
+    for (int e = 0; e < E; ++e) {
+        float acc = __shfl(logit_e, e, 64) + bg[e];
         if (lc_out && lane == 0) lc_out[(int64_t)n * E + e] = acc;
         float z = acc + (gen ? __shfl(my_draw, e, 64) : g2[(int64_t)n * E + e]);
         if (z > best) { best = z; bi = e; }
@@ -342,9 +397,12 @@ __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __r
         ic[n] = bi;
         const float* lar = la + (int64_t)(n % la_rows) * E;
         float bz = -INFINITY; int ba = 0;
-        for (int e = 0; e < E; ++e) {
-            float z = lar[e] + (gen ? d3[e] : g3[(int64_t)n * E + e]);
-            if (z > bz) { bz = z; ba = e; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < E) {
+                float z = lar[e] + (gen ? d3[e] : g3[(int64_t)n * E + e]);
+                if (z > bz) { bz = z; ba = e; }
+            }
         }
         ia[n] = ba;
         const int b = bb;
@@ -385,70 +443,78 @@ int launch_router_top1(const float* logits, const float* gumbel, int N, int E, i
 }
 
 // ---------------------------------------------------------------------------
-// Stable bucketing of tokens by routed expert: slots [0,N) caption groups, [N,2N) acoustic
-// groups; perm[slot] = token, group_off[2E+1].  One 1024-thread block (deterministic order).
+// Stable bucketing of tokens by routed expert: slots [0,N) caption groups, [N,2N) acoustic groups;
+// perm[slot] = token, group_off[2E+1].  Two multi-block kernels (deterministic, ascending token order inside a group):
+//   bucket_count : per 256-token block, per group counts (wave ballots)       -> counts[nblk][2E]
+//   bucket_place : every block re-derives its bases from the small counts table, ranks its tokens with ballots and
+//                  writes perm; block 0 also writes group_off.
+// `counts` lives right behind perm's 2N entries (perm buffers are sized 2N + nblk*2E + 64 by the engine).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) bucket_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
-                                                     int* group_off, int* perm) {
-    extern __shared__ int cnt[];            // [2E][1024] counts -> exclusive prefixes ; then [2E] totals
-    int* tot = cnt + 2 * E * 1024;
-    const int tid = threadIdx.x;
-    const int chunk = (N + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(N, lo + chunk);
-    for (int gI = 0; gI < 2 * E; ++gI) cnt[gI * 1024 + tid] = 0;
-    for (int n = lo; n < hi; ++n) {
-        cnt[ic[n] * 1024 + tid] += 1;
-        cnt[(E + ia[n]) * 1024 + tid] += 1;
+#define BK_T 256
+__global__ void __launch_bounds__(BK_T) bucket_count_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
+                                                           int* counts) {
+    __shared__ int wc[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x * BK_T + tid;
+    const int gc = n < N ? ic[n] : -1, ga = n < N ? E + ia[n] : -1;
+    for (int g = 0; g < 2 * E; ++g) {
+        const unsigned long long m = __ballot(g < E ? (gc == g) : (ga == g));
+        if (lane == 0) wc[wave][g] = __popcll(m);
     }
     __syncthreads();
-    // wave w scans group w (and w+16 ...) across the 1024 per-thread counters
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int gI = wave; gI < 2 * E; gI += 16) {
-        int carry = 0;
-        for (int base = 0; base < 1024; base += 64) {
-            int v = cnt[gI * 1024 + base + lane];
-            int inc = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                int t = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += t;
-            }
-            cnt[gI * 1024 + base + lane] = carry + inc - v;
-            carry += __shfl(inc, 63, 64);
+    if (tid < 2 * E) counts[blockIdx.x * 2 * E + tid] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+}
+__global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
+                                                           const int* __restrict__ counts, int nblk, int* group_off, int* perm) {
+    __shared__ int base[32];        // slot of this block's first token of every group
+    __shared__ int wc[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = 2 * E;
+    if (tid < G) {
+        // group start = sum of all earlier groups' totals; + this group's tokens in earlier blocks
+        int before_groups = 0, before_blocks = 0;
+        for (int b = 0; b < nblk; ++b) {
+            for (int g = 0; g < tid; ++g) before_groups += counts[b * G + g];
+            if (b < (int)blockIdx.x) before_blocks += counts[b * G + tid];
         }
-        if (lane == 0) tot[gI] = carry;
+        base[tid] = before_groups + before_blocks;
+        if (blockIdx.x == 0) {
+            group_off[tid] = before_groups;
+            if (tid == G - 1) {
+                int tot = 0;
+                for (int b = 0; b < nblk; ++b) tot += counts[b * G + tid];
+                group_off[G] = before_groups + tot;
+            }
+        }
+    }
+    const int n = blockIdx.x * BK_T + tid;
+    const int gc = n < N ? ic[n] : -1, ga = n < N ? E + ia[n] : -1;
+    int rank_c = 0, rank_a = 0;
+    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int g = 0; g < G; ++g) {
+        const unsigned long long m = __ballot(g < E ? (gc == g) : (ga == g));
+        if (lane == 0) wc[wave][g] = __popcll(m);
+        if (g == gc) rank_c = __popcll(m & lower);
+        if (g == ga) rank_a = __popcll(m & lower);
     }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int gI = 0; gI < 2 * E; ++gI) { group_off[gI] = acc; acc += tot[gI]; }
-        group_off[2 * E] = acc;
-    }
-    __syncthreads();
-    // bases are recomputed from tot[] (group_off lives in global memory, written by thread 0 only)
-    for (int n = lo; n < hi; ++n) {
-        int gc = ic[n], ga = E + ia[n];
-        int oc = 0, oa = 0;
-        for (int gI = 0; gI < gc; ++gI) oc += tot[gI];
-        for (int gI = 0; gI < ga; ++gI) oa += tot[gI];
-        int pc = cnt[gc * 1024 + tid]++;
-        int pa = cnt[ga * 1024 + tid]++;
-        perm[oc + pc] = n;
-        perm[oa + pa] = n;
+    if (n < N) {
+        int pc = base[gc] + rank_c, pa = base[ga] + rank_a;
+        for (int w = 0; w < wave; ++w) { pc += wc[w][gc]; pa += wc[w][ga]; }
+        perm[pc] = n;
+        perm[pa] = n;
     }
 }
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st) {
     if (E > 16) VB_FAIL(VB_E_INVALID, "bucket: E=%d > 16", E);
-    size_t sh = (size_t)(2 * E * 1024 + 2 * E) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(bucket_kernel, dim3(1), dim3(1024), sh, st, ic, ia, N, E, group_off, perm);
+    const int nblk = cdiv(N, BK_T);
+    int* counts = perm + 2 * (size_t)N;          // scratch tail of the perm buffer (see bucket_scratch_ints)
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, counts);
+    hipLaunchKernelGGL(bucket_place_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, counts, nblk, group_off, perm);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
+int bucket_scratch_ints(int N, int E) { return cdiv(N, BK_T) * 2 * E + 64; }
 
 // ---------------------------------------------------------------------------
 // Gumbel noise generator for the production path: G = -log(-log(1-u)), u from splitmix64

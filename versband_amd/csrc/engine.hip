@@ -148,7 +148,7 @@ static WsL carve_ws(void* base, const vb_dit_config& c, int B, int nb, int T, in
     o.ic = cv.take<int>(N);
     o.ia = cv.take<int>(N);
     o.group_off = cv.take<int>(2 * E + 1);
-    o.perm = cv.take<int>(2 * N);
+    o.perm = cv.take<int>(2 * N + bucket_scratch_ints((int)N, E));
     // precompute temporaries
     const int T_mel = 2 * T + 8;
     o.tA = cv.take<float>((size_t)B * D * T_mel);
@@ -616,6 +616,7 @@ int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, cons
 int vb_router_top1(const float* logits, const float* gumbel, int N, int E, int32_t* idx, void* stream) {
     return launch_router_top1(logits, gumbel, N, E, idx, (hipStream_t)stream);
 }
+int vb_route_bucket_scratch_ints(int N, int E) { return bucket_scratch_ints(N, E); }
 int vb_route_bucket(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, void* stream) {
     return launch_bucket(ic, ia, N, E, group_off, perm, (hipStream_t)stream);
 }

@@ -114,6 +114,7 @@ int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, 
                   hipStream_t st);
 int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st);
+int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this many ints
 int launch_router_top1(const float* logits, const float* gumbel, int N, int E, int* idx, hipStream_t st);
 int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
                        const int* step, int block, int gate, hipStream_t st);
