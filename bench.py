@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--flow-steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
     ap.add_argument("--scale", type=float, default=3.0)
+    ap.add_argument("--streams", type=int, default=2, help="independent sub-batches per GPU, one HIP stream + host thread each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-flow-steps", type=int, default=4)
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
@@ -212,22 +213,41 @@ def main():
         sds = broadcast_state(sds, rank, world, device)
     log("weights ready; packing")
     ctx = Context(device)
-    eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision)
-    vae = build_vae_decoder(ctx, sds[1])
-    voc = build_hifigan(ctx, sds[2], hcfg.as_hparams())
-
+    S = max(1, args.streams)
     B = args.batch
-    inp = clip_batch(B, T_LAT, L_CTX, clip0=rank * B, seed=SEED)
-    x0 = inp["x_latent"].to(device)
-    t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device)
-    midi, beats = inp["midi"].to(device), inp["beats"].to(device)
+    assert B % S == 0, "--batch must be divisible by --streams"
+    Bs = B // S
     idx, dts = vm.euler_tables(args.flow_steps + 1)
+    # S independent sub-batches, each with its own engine handles, on its own HIP stream driven by its own host thread:
+    # kernels of different sub-batches overlap on the GPU and fill each other's tile-quantisation tails.
+    workers = []
+    for si in range(S):
+        eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision)
+        vae = build_vae_decoder(ctx, sds[1])
+        voc = build_hifigan(ctx, sds[2], hcfg.as_hparams())
+        inp = clip_batch(Bs, T_LAT, L_CTX, clip0=rank * B + si * Bs, seed=SEED)
+        workers.append(dict(eng=eng, vae=vae, voc=voc, x0=inp["x_latent"].to(device),
+                            t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
+                            beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=rank * B + si * Bs,
+                            wav=None))
 
-    def one_pass(k):
-        cond = eng.precompute_cond(t5, midi, beats, T_LAT)
-        z = eng.sample_cfg(x0, cond, idx, dts, args.scale, seed=SEED + k, clip_base=rank * B)
-        mel = vae.run(z)
-        return voc.run(mel)
+    def run_worker(w, ks):
+        with torch.cuda.stream(w["stream"]):
+            for k in ks:
+                cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_LAT)
+                z = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + k, clip_base=w["clip_base"])
+                w["wav"] = w["voc"].run(w["vae"].run(z))
+
+    def run_passes(ks):
+        import threading
+        if S == 1:
+            run_worker(workers[0], ks)
+        else:
+            ths = [threading.Thread(target=run_worker, args=(w, ks)) for w in workers]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
 
     def barrier():
         torch.cuda.synchronize()
@@ -237,35 +257,55 @@ def main():
             torch.cuda.synchronize()
 
     lib = L.load()
-    log("engines built; warmup")
+    torch.cuda.synchronize()
+    log(f"engines built ({S} stream(s) x {Bs} clips); warmup")
 
     def read_prof(cls):
         ms, fl, n, nt = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
         L.check(lib.vb_prof_read(cls, C.byref(ms), C.byref(fl), C.byref(n), C.byref(nt)), "vb_prof_read")
         return ms.value, fl.value, n.value, nt.value
 
-    # warmup; the last warmup pass times every kernel class to find the dominant one
-    dominant, breakdown = 2, {}
-    for w in range(max(args.warmup, 1)):
-        last = w == max(args.warmup, 1) - 1
+    # warmup; the last warmup pass times (a sample of) every kernel class to find the dominant one
+    EVERY = 4
+    dominant, breakdown = 0, {}
+    for wi in range(max(args.warmup, 1)):
+        last = wi == max(args.warmup, 1) - 1
         if last:
-            L.check(lib.vb_prof_enable(7), "prof")
-        wav = one_pass(-1 - w)
+            L.check(lib.vb_prof_enable(7 | (EVERY << 8)), "prof")
+        run_passes([-1 - wi])
         torch.cuda.synchronize()
         if last:
             for cls in (0, 1, 2):
                 ms, fl, n, nt = read_prof(cls)
-                # launches beyond the event pool are extrapolated from the timed ones
-                breakdown[cls] = ms * (n / nt) if nt else 0.0
+                breakdown[cls] = ms * (n / nt) if nt else 0.0      # sampled launches extrapolated to the class
             dominant = max(breakdown, key=breakdown.get)
-    assert torch.isfinite(wav).all()
-    L.check(lib.vb_prof_enable(1 << dominant), "prof")
+    assert all(torch.isfinite(w["wav"]).all() for w in workers)
+    # the dominant class alone on the GPU (one stream, the whole batch of B clips): the kernel-quality figure that the
+    # concurrent timed region dilutes (two sub-batches share the CUs, so each launch is slower but two are in flight)
+    isolated = None
+    if S > 1:
+        inp = clip_batch(B, T_LAT, L_CTX, clip0=rank * B, seed=SEED)
+        w = dict(eng=DiTEngine(ctx, dcfg, sds[0], precision=args.precision), vae=build_vae_decoder(ctx, sds[1]),
+                 voc=build_hifigan(ctx, sds[2], hcfg.as_hparams()), x0=inp["x_latent"].to(device),
+                 t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
+                 beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=rank * B, wav=None)
+        run_worker(w, [-100])
+        torch.cuda.synchronize()
+        L.check(lib.vb_prof_enable((1 << dominant) | (EVERY << 8)), "prof")
+        run_worker(w, [-101])
+        torch.cuda.synchronize()
+        ms, fl, n, nt = read_prof(dominant)
+        if ms > 0 and nt > 0:
+            isolated = {"achieved": fl / (ms * 1e-3) / 1e12, "avg_launch_us": 1e3 * ms / nt, "timed_launches": nt,
+                        "what": f"same class, one stream, one batch of {B} clips (nothing else on the GPU)"}
+        del w
+        torch.cuda.empty_cache()
+    L.check(lib.vb_prof_enable((1 << dominant) | (EVERY << 8)), "prof")
     log(f"warmup done; class ms/pass = {breakdown}; timing {args.steps} step(s)")
 
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        wav = one_pass(k)
+    run_passes(list(range(args.steps)))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -279,7 +319,7 @@ def main():
 
     if rank == 0:
         bound, peak, kname = PEAK[dominant]
-        achieved = (fl * (nt / n) / (ms * 1e-3) / 1e12) if (ms > 0 and n > 0) else 0.0
+        achieved = (fl / (ms * 1e-3) / 1e12) if (ms > 0 and nt > 0) else 0.0      # flops and time of the timed launches
         total_mel_s = world * B * CLIP_SECONDS * args.steps
         out = {
             "metric": "mel-seconds generated/sec (20 s clip, %d flow steps)" % args.flow_steps,
@@ -298,12 +338,15 @@ def main():
             "config": {"workload": f"{B} x 20 s clips per GPU (T_lat=752, T_mel=1504, 24 kHz), {args.flow_steps} Euler steps x 2 NFE (CFG "
                                    f"scale {args.scale}), Band-MoE E=4, VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml",
                        "clips_per_gpu": B, "flow_steps": args.flow_steps, "precision": args.precision,
-                       "parallelism": f"batch-shard x{world}"},
+                       "streams_per_gpu": S, "parallelism": f"batch-shard x{world} ({S} concurrent sub-batches of {Bs} clips per GPU)"},
             "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc_traffic(dominant),
                          "traffic_note": "HBM bytes per launch averaged over the class, from the committed rocprofv3 --pmc FETCH_SIZE / "
                                          "WRITE_SIZE passes of this command (profiles/r01_pmc_summary.json); algorithmic bytes in DESIGN.md",
                          "avg_launch_us": (1e3 * ms / nt) if nt else None, "launches_per_step": n / max(args.steps, 1),
+                         "timed_launches": nt, "note": "every 4th launch of the class is bracketed by HIP events on its own stream; with "
+                         "streams_per_gpu > 1 a launch shares the GPU with the other sub-batch's kernels, so its duration includes that overlap",
+                         "isolated": (dict(isolated, frac=isolated["achieved"] / peak) if isolated else None),
                          "class_ms_per_step_warmup": {PEAK[c][2]: round(v, 3) for c, v in breakdown.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -44,7 +44,8 @@ int vb_abi_version(void);
 /* HIP-event timing of one kernel class inside a region (bench.py roofline): bit 0 = bf16 GEMM,
  * bit 1 = attention, bit 2 = fp32 conv.  Events are recorded on the launch stream around every launch of
  * the enabled classes; vb_prof_read synchronises the device and sums the elapsed times.
- * flops = algorithmic FLOPs of the counted launches (2*M*N*K, 4*B*H*T*S*hd, 2*B*Co*Ci*k*T). */
+ * Bits 8..15 of class_mask = sampling period n (time every n-th launch of a class per host thread; 0/1 = every launch).
+ * vb_prof_read: ms_sum and flops cover the `timed` launches only; `launches` counts all launches of the class. */
 int vb_prof_enable(int class_mask);
 int vb_prof_read(int cls, double* ms_sum, double* flops, int64_t* launches, int64_t* timed);
 

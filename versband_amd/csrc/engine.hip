@@ -5,6 +5,7 @@
 // caller buffers (sizes from *_bytes()).
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/versband_hip.h"
@@ -23,12 +24,17 @@ static std::vector<ProfRec> g_prof_recs;
 static double g_prof_flops[PROF_CLASSES] = {0, 0, 0};
 static long long g_prof_launches[PROF_CLASSES] = {0, 0, 0};
 static thread_local size_t g_prof_open = (size_t)-1;
+static thread_local unsigned g_prof_tick[PROF_CLASSES] = {0, 0, 0};
+static int g_prof_every = 1;                        // time every n-th launch of a class (per host thread)
+static std::mutex g_prof_mu;                        // several host threads (one per stream) may launch concurrently
 void prof_start(int cls, double flops, hipStream_t st) {
     g_prof_open = (size_t)-1;
     if (!(g_prof_mask & (1 << cls))) return;
-    g_prof_flops[cls] += flops;
+    const bool sampled = (g_prof_tick[cls]++ % (unsigned)g_prof_every) == 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_launches[cls] += 1;
-    if (g_prof_next + 2 > g_prof_ev.size()) return;      // pool exhausted: launch counted, not timed
+    if (!sampled || g_prof_next + 2 > g_prof_ev.size()) return;      // counted, not timed
+    g_prof_flops[cls] += flops;
     g_prof_open = g_prof_next;
     g_prof_next += 2;
     (void)hipEventRecord(g_prof_ev[g_prof_open], st);
@@ -36,7 +42,10 @@ void prof_start(int cls, double flops, hipStream_t st) {
 void prof_stop(int cls, hipStream_t st) {
     if (g_prof_open == (size_t)-1) return;
     (void)hipEventRecord(g_prof_ev[g_prof_open + 1], st);
-    g_prof_recs.push_back(ProfRec{cls, g_prof_open});
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_recs.push_back(ProfRec{cls, g_prof_open});
+    }
     g_prof_open = (size_t)-1;
 }
 
@@ -468,7 +477,8 @@ int vb_prof_enable(int class_mask) {
         g_prof_ev.resize(2 * PROF_POOL);
         for (auto& e : g_prof_ev) VB_HIP(hipEventCreate(&e));
     }
-    g_prof_mask = class_mask;
+    g_prof_mask = class_mask & 0xff;
+    g_prof_every = ((class_mask >> 8) & 0xff) > 0 ? ((class_mask >> 8) & 0xff) : 1;     // bits 8..15: sampling period
     g_prof_next = 0;
     g_prof_recs.clear();
     for (int i = 0; i < PROF_CLASSES; ++i) { g_prof_flops[i] = 0; g_prof_launches[i] = 0; }
