@@ -266,7 +266,7 @@ def main():
         return ms.value, fl.value, n.value, nt.value
 
     # warmup; the last warmup pass times (a sample of) every kernel class to find the dominant one
-    EVERY = 4
+    EVERY = 5            # coprime with the 4 GEMMs / block so the sample walks over every kernel of the class
     dominant, breakdown = 0, {}
     for wi in range(max(args.warmup, 1)):
         last = wi == max(args.warmup, 1) - 1
@@ -344,7 +344,7 @@ def main():
                          "traffic_note": "HBM bytes per launch averaged over the class, from the committed rocprofv3 --pmc FETCH_SIZE / "
                                          "WRITE_SIZE passes of this command (profiles/r01_pmc_summary.json); algorithmic bytes in DESIGN.md",
                          "avg_launch_us": (1e3 * ms / nt) if nt else None, "launches_per_step": n / max(args.steps, 1),
-                         "timed_launches": nt, "note": "every 4th launch of the class is bracketed by HIP events on its own stream; with "
+                         "timed_launches": nt, "note": "every 5th launch of the class is bracketed by HIP events on its own stream; with "
                          "streams_per_gpu > 1 a launch shares the GPU with the other sub-batch's kernels, so its duration includes that overlap",
                          "isolated": (dict(isolated, frac=isolated["achieved"] / peak) if isolated else None),
                          "class_ms_per_step_warmup": {PEAK[c][2]: round(v, 3) for c, v in breakdown.items()}},

@@ -152,8 +152,11 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
  * AutoencoderKL.decode (ldm/models/autoencoder1d.py:55-58, Decoder1D :480-512) and
  * HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) both run as a flat op
  * list over fp32 [B][C][T] buffers; the list is built from the model config by the host side. */
-typedef struct { int channels; int tmul; int square; } vb_buf_desc;
-enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2 };
+typedef struct { int channels; int tmul; int square; } vb_buf_desc;   /* square: 1 = [T*tmul]^2 floats, 2 = channels x roundup(T*tmul, 32) */
+/* VB_OP_SPLIT_PLANES: x (f32 [B][rows][cols], rows = Co, cols = Ci, -1 = the buffer's time length) -> out = split-bf16
+ * planes [2][B][rows][roundup(cols, 32)]; a later VB_OP_CONV with w_buf = that buffer and ci_pad = -1 uses them as
+ * per-batch weights on the bf16x3 kernel (the VAE decoder's single-head attention) */
+enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3 };
 enum { VB_ACT_NONE = 0, VB_ACT_LRELU = 1, VB_ACT_GN_SWISH = 2, VB_ACT_TANH = 3, VB_ACT_GN = 4 };
 #define VB_BUF_INPUT (-2)
 #define VB_BUF_OUTPUT (-3)

@@ -229,6 +229,25 @@ def test_determinism_and_clip_keyed_noise(engines):
     assert torch.equal(a[sel], c), describe("clip 2 alone vs in batch", c, a[sel])
 
 
+def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
+    """The launcher picks the GEMM tile shape (128x128 two-per-CU kernel or the 192x192 one-per-CU kernel) from the
+    problem size, i.e. from the batch: both must produce bit-identical DiT outputs and routes, otherwise a clip's
+    result would depend on the batch it rides in (hard routing amplifies a 1-ulp difference into an expert flip)."""
+    eng = engines[(4, "bf16")]
+    B, T, Lc = 2, 752, 80
+    inp = clip_batch(B, T, Lc)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2 * B,), 321, dtype=torch.int64)
+    outs = []
+    for cfg in ("22", "33"):
+        monkeypatch.setenv("VB_GEMM_TILE", cfg)
+        v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
+        torch.cuda.synchronize()
+        outs.append((v.clone(), r.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 def test_full_size_properties(ctx, engines):
     """BASELINE geometry (T=752, L=80): size-independent checks - finite outputs, CFG with scale 1 equals the
     conditional-only path, padding frames beyond T never leak (Tpad masking), full-length VAE/vocoder shapes."""

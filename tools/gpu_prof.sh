@@ -5,11 +5,11 @@ mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/trace -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/trace -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $R/gpurun_out/prof/trace.log 2>&1
 tail -3 $R/gpurun_out/prof/trace.log
 if [ "${1:-}" = "pmc" ]; then
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof/fetch -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/fetch.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof/write -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/write.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof/fetch -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $R/gpurun_out/prof/fetch.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof/write -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $R/gpurun_out/prof/write.log 2>&1
 fi
 cd $R
 find gpurun_out/prof -name "*stats*" | head

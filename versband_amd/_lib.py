@@ -56,7 +56,7 @@ class NetOp(C.Structure):
                 + [("w_x3", c_void_p), ("ci_pad", c_int)])
 
 
-OP_CONV, OP_GN_STATS, OP_SOFTMAX_T = 0, 1, 2
+OP_CONV, OP_GN_STATS, OP_SOFTMAX_T, OP_SPLIT_PLANES = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_GN_SWISH, ACT_TANH, ACT_GN = 0, 1, 2, 3, 4
 BUF_INPUT, BUF_OUTPUT = -2, -3
 NET_VAE, NET_VOCODER = 0, 1

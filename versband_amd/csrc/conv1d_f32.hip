@@ -35,6 +35,7 @@ struct ConvDev {
     int out_transposed; const float* add; int64_t add_bstride; int add_bmod;
     int phases, tr_pad;      // phases == 1: ordinary convolution
     const bf16_t* wp; int64_t wp_plane; int Ci_pad;   // split-bf16 weights [2 planes][phase][tap][Co][Ci_pad]
+    int64_t wp_bstride;
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -279,7 +280,7 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
     const int T_eff = p.upsample2 ? 2 * p.T_in : p.T_in;
     const int xb = p.x_bmod > 0 ? (b % p.x_bmod) : b;
     const float* xbase = p.x + (int64_t)xb * p.x_bstride;
-    const bf16_t* wbase = p.wp + (int64_t)ph * p.ntaps * p.Co * p.Ci_pad;
+    const bf16_t* wbase = p.wp + (int64_t)b * p.wp_bstride + (int64_t)ph * p.ntaps * p.Co * p.Ci_pad;
     const int cpg = p.gn_groups > 0 ? (p.Ci / p.gn_groups) : 1;
 
     f32x16 acc[TM][TN];
@@ -461,7 +462,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     d.out = a.out; d.out_bstride = a.out_bstride; d.T_out = a.T_out; d.res = a.res; d.res_bstride = a.res_bstride;
     d.alpha = a.alpha; d.beta = a.beta; d.acc_scale = a.acc_scale; d.out_act = a.out_act; d.out_slope = a.out_slope;
     d.out_transposed = a.out_transposed; d.add = a.add; d.add_bstride = a.add_bstride; d.add_bmod = a.add_bmod;
-    d.wp = a.wp; d.wp_plane = a.wp_plane; d.Ci_pad = a.Ci_pad;
+    d.wp = a.wp; d.wp_plane = a.wp_plane; d.Ci_pad = a.Ci_pad; d.wp_bstride = a.wp_bstride;
     int n_count;
     if (a.tr_stride > 1) {
         d.phases = a.tr_stride; d.tr_pad = a.tr_pad; d.ntaps = (a.tr_k + a.tr_stride - 1) / a.tr_stride; d.dil = 1;
@@ -474,7 +475,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if (a.out_transposed && (a.Co % 4)) VB_FAIL(VB_E_INVALID, "conv1d: transposed output needs Co%%4==0");
     if ((a.in_act == ACT_GN_SWISH || a.in_act == ACT_GN) && (a.Ci % a.gn_groups)) VB_FAIL(VB_E_INVALID, "conv1d: Ci %% groups");
     ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * (a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize), st);
-    if (a.wp && !a.w_bstride) {
+    if (a.wp && (!a.w_bstride || a.wp_bstride)) {
         if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
         // VB_CONV_CFG (tuning knob): 1 = wide-T tile (64co x 256t) for 32 < Co <= 64
         const char* ev = getenv("VB_CONV_CFG");

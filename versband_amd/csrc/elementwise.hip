@@ -122,6 +122,31 @@ int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st) {
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
+__global__ void split_rows_kernel(const float* __restrict__ x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane) {
+    const int q = cpad >> 2;
+    const int64_t total = rows * q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / q;
+        const int c = (int)(i - r * q) * 4;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (c + k < cols) ? x[r * cols + c + k] : 0.f;
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hi[k] = f2bf(v[k]); lo[k] = f2bf(v[k] - bf2f(hi[k])); }
+        *reinterpret_cast<bf16x4*>(out + r * cpad + c) = hi;
+        *reinterpret_cast<bf16x4*>(out + plane + r * cpad + c) = lo;
+    }
+}
+int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st) {
+    if (cpad % 4 || cpad < cols) VB_FAIL(VB_E_INVALID, "split_rows: cpad=%d cols=%d", cpad, cols);
+    int64_t blocks = (rows * (cpad / 4) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((int)blocks), dim3(256), 0, st, x, rows, cols, cpad, out, plane);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
 __global__ void planes_to_f32_kernel(Planes in, int64_t n, float* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -309,118 +334,149 @@ __device__ __forceinline__ float reduce_logits(const float (&part)[16], int lane
 //   lc = cq . Wg^T + bg ; ic = argmax(lc + G2) ; ia = argmax(la + G3) (first maximum wins, like
 //   torch.max) ; (m_c, m_a) = softmax(hl[b] + G1).   G* are Gumbel draws (-log Exp(1)).
 // ---------------------------------------------------------------------------
+#define RT_TPW 4      // tokens per wave
+template <int PP>     // tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, else 1
 __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __restrict__ Wg,
                                                     const float* __restrict__ bg, const float* __restrict__ la, int la_rows,
                                                     const float* __restrict__ hl, int hl_ld, const float* __restrict__ g1,
                                                     const float* __restrict__ g2, const float* __restrict__ g3, int N, int T, int D,
                                                     int E, int* ic, int* ia, float* mc, float* ma, float* lc_out, int B, uint64_t seed,
                                                     int64_t clip_base, int nfe_base, const int* step, int block) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // gate weights staged once per block (every wave re-reading E*D floats per token through L1/L2 was the kernel's
+    // whole cost); a wave then walks RT_TPW tokens
+    extern __shared__ float rt_ws[];
+    for (int i = threadIdx.x * 4; i < E * D; i += 256 * 4) *reinterpret_cast<float4*>(rt_ws + i) = *reinterpret_cast<const float4*>(Wg + i);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    if (n >= N) return;
-    const bf16_t* xh = cq.p + (int64_t)n * D;
-    // noise source: injected arrays, or draws keyed by (seed, global clip, nfe, branch, block, gate, token)
-    const bool gen = g1 == nullptr;
-    const int bb = n / T, tt = n - bb * T;
-    const int branch = bb / B;
-    const int64_t clip = clip_base + (bb - branch * B);
-    const int nfe = nfe_base + (step ? *step : 0);
-    // lanes [0,E): caption-gate draws, [E,2E): acoustic-gate draws, 2E, 2E+1: high-level gate draws (one draw per lane)
-    float my_draw = 0.f;
-    if (gen && lane < 2 * E + 2) {
-        const int gate = lane < E ? 1 : (lane < 2 * E ? 2 : 0);
-        const int slot = lane < E ? lane : (lane < 2 * E ? lane - E : lane - 2 * E);
-        my_draw = gumbel_draw(seed, clip, nfe, branch, block, gate, tt, gate == 0 ? 2 : E, slot);
-    }
-    // token features = MoE cross-attention output (bf16 planes); Wg/bg already contain out_proj folded in
-    float xv[12];      // D <= 768: 3 x 4 values per lane
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RT_TPW;
+    if (n0 >= N) return;
+    // phase A: the RT_TPW tokens' feature loads are issued together (token features = MoE cross-attention output, bf16
+    // planes; Wg/bg already contain out_proj folded in), then E partial dot products per lane and token
+    float parts[RT_TPW][16];
+    {
+        float xv[RT_TPW][12];      // D <= 768: 3 x 4 values per lane
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int k = lane * 4 + i * 256;
-        if (k < D) {
-            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(xh + k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[i * 4 + j] = bf2f(hv[j]);
-            if (cq.np == 2) {
-                const bf16x4 lv = *reinterpret_cast<const bf16x4*>(xh + cq.plane + k);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xv[i * 4 + j] += bf2f(lv[j]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[i * 4 + j] = 0.f;
-        }
-    }
-    // E partial dot products per lane, reduced together: after exchanging with lane^32 a lane keeps half of the
-    // experts, after lane^16 a quarter, ... then the remaining value is summed over the rest of the wave
-    // (7 shuffles for E = 4 instead of 24); lane e then holds logit e.
-    float part[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float acc = 0.f;
-        if (e < E) {
+        for (int tok = 0; tok < RT_TPW; ++tok) {
+            const bf16_t* xh = cq.p + (int64_t)min(n0 + tok, N - 1) * D;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int k = lane * 4 + i * 256;
                 if (k < D) {
-                    const float4 wv = *reinterpret_cast<const float4*>(Wg + (int64_t)e * D + k);
-                    acc += xv[i * 4] * wv.x + xv[i * 4 + 1] * wv.y + xv[i * 4 + 2] * wv.z + xv[i * 4 + 3] * wv.w;
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(xh + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[tok][i * 4 + j] = bf2f(hv[j]);
+                    if (cq.np == 2) {
+                        const bf16x4 lv = *reinterpret_cast<const bf16x4*>(xh + cq.plane + k);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xv[tok][i * 4 + j] += bf2f(lv[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[tok][i * 4 + j] = 0.f;
                 }
             }
         }
-        part[e] = acc;
-    }
-    float logit_e = 0.f;      // valid on lanes [0,E)
-    if (E == 4) logit_e = reduce_logits<4>(part, lane);
-    else if (E == 8) logit_e = reduce_logits<8>(part, lane);
-    else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
+            float acc[RT_TPW];
+#pragma unroll
+            for (int tok = 0; tok < RT_TPW; ++tok) acc[tok] = 0.f;
             if (e < E) {
-                const float r = wave_sum(part[e]);
-                if (lane == e) logit_e = r;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int k = lane * 4 + i * 256;
+                    if (k < D) {
+                        const float4 wv = *reinterpret_cast<const float4*>(rt_ws + e * D + k);
+#pragma unroll
+                        for (int tok = 0; tok < RT_TPW; ++tok)
+                            acc[tok] += xv[tok][i * 4] * wv.x + xv[tok][i * 4 + 1] * wv.y + xv[tok][i * 4 + 2] * wv.z + xv[tok][i * 4 + 3] * wv.w;
+                    }
+                }
             }
+#pragma unroll
+            for (int tok = 0; tok < RT_TPW; ++tok) parts[tok][e] = acc[tok];
         }
     }
-    float best = -INFINITY; int bi = 0;
-    for (int e = 0; e < E; ++e) {
-        float acc = __shfl(logit_e, e, 64) + bg[e];
-        if (lc_out && lane == 0) lc_out[(int64_t)n * E + e] = acc;
-        float z = acc + (gen ? __shfl(my_draw, e, 64) : g2[(int64_t)n * E + e]);
-        if (z > best) { best = z; bi = e; }
-    }
-    float d3[16];
+    // phase B: noise draws, logit reduction, arg-max, high-level gate.  A token needs 2E+2 "slots" (E caption-gate,
+    // E acoustic-gate, 2 high-level-gate values): PP tokens are laid side by side in the wave (SPT = 64/PP lanes each), so
+    // the counter-based noise generator, the index arithmetic and the arg-max loops run once per PP tokens.
+    constexpr int SPT = 64 / PP;
+    const bool gen = g1 == nullptr;
+    const int nfe = nfe_base + (step ? *step : 0);
+    const int tokq = lane / SPT, sl = lane % SPT, lbase = lane - sl;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) d3[e] = (gen && e < E) ? __shfl(my_draw, E + e, 64) : 0.f;
-    const float d10 = gen ? __shfl(my_draw, 2 * E, 64) : 0.f, d11 = gen ? __shfl(my_draw, 2 * E + 1, 64) : 0.f;
-    if (lane == 0) {
-        ic[n] = bi;
-        const float* lar = la + (int64_t)(n % la_rows) * E;
-        float bz = -INFINITY; int ba = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (e < E) {
-                float z = lar[e] + (gen ? d3[e] : g3[(int64_t)n * E + e]);
-                if (z > bz) { bz = z; ba = e; }
-            }
+    for (int t0 = 0; t0 < RT_TPW; t0 += PP) {
+        const int n = n0 + t0 + tokq;
+        const bool valid = n < N;
+        const int nn = valid ? n : N - 1;
+        const int bb = nn / T, tt = nn - bb * T;
+        const int branch = bb / B;
+        const int64_t clip = clip_base + (bb - branch * B);
+        const int gate = sl < E ? 1 : (sl < 2 * E ? 2 : 0);
+        const int slot = sl < E ? sl : (sl < 2 * E ? sl - E : sl - 2 * E);
+        // this lane's side input: caption gate bias / acoustic gate logit / high-level gate logit; and its noise value
+        float sv = 0.f, nz = 0.f;
+        if (sl < 2 * E + 2) {
+            if (gate == 1) sv = bg[slot];
+            else if (gate == 2) sv = la[(int64_t)(nn % la_rows) * E + slot];
+            else sv = hl[bb * hl_ld + slot];
+            if (gen) nz = gumbel_draw(seed, clip, nfe, branch, block, gate, tt, gate == 0 ? 2 : E, slot);
+            else nz = gate == 1 ? g2[(int64_t)nn * E + slot] : (gate == 2 ? g3[(int64_t)nn * E + slot] : g1[(int64_t)nn * 2 + slot]);
         }
-        ia[n] = ba;
-        const int b = bb;
-        float z0 = hl[b * hl_ld + 0] + (gen ? d10 : g1[(int64_t)n * 2 + 0]);
-        float z1 = hl[b * hl_ld + 1] + (gen ? d11 : g1[(int64_t)n * 2 + 1]);
-        float m = fmaxf(z0, z1);
-        float e0 = expf(z0 - m), e1 = expf(z1 - m);
-        float inv = 1.f / (e0 + e1);
-        mc[n] = e0 * inv;
-        ma[n] = e1 * inv;
+        // E partial dot products per lane, reduced together: after exchanging with lane^32 a lane keeps half of the
+        // experts, after lane^16 a quarter, ... then the remaining value is summed over the rest of the wave
+        // (7 shuffles for E = 4 instead of 24); lane e then holds logit e, from where the token's own lanes fetch it.
+        float mylogit = 0.f;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const float (&part)[16] = parts[t0 + j];
+            float logit_e = 0.f;      // valid on lanes [0,E)
+            if (E == 4) logit_e = reduce_logits<4>(part, lane);
+            else if (E == 8) logit_e = reduce_logits<8>(part, lane);
+            else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (e < E) {
+                        const float r = wave_sum(part[e]);
+                        if (lane == e) logit_e = r;
+                    }
+                }
+            }
+            const float v = __shfl(logit_e, sl < E ? sl : 0, 64);
+            if (tokq == j) mylogit = v;
+        }
+        const float zl = (sl < E ? mylogit : 0.f) + sv;      // gate logit of this lane's (token, gate, slot)
+        if (lc_out && valid && sl < E) lc_out[(int64_t)n * E + sl] = zl;
+        const float z = zl + nz;
+        float best = -INFINITY, bz = -INFINITY; int bi = 0, ba = 0;
+        for (int e = 0; e < E; ++e) {
+            const float zc = __shfl(z, lbase + e, 64), za = __shfl(z, lbase + E + e, 64);
+            if (zc > best) { best = zc; bi = e; }
+            if (za > bz) { bz = za; ba = e; }
+        }
+        const float z0 = __shfl(z, lbase + 2 * E, 64), z1 = __shfl(z, lbase + 2 * E + 1, 64);
+        if (valid && sl == 0) {
+            ic[n] = bi;
+            ia[n] = ba;
+            const float m = fmaxf(z0, z1);
+            const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+            const float inv = 1.f / (e0 + e1);
+            mc[n] = e0 * inv;
+            ma[n] = e1 * inv;
+        }
     }
 }
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
                   hipStream_t st) {
-    hipLaunchKernelGGL(router_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E, ic,
-                       ia, mc, ma, lc_out, B > 0 ? B : 1, seed, clip_base, nfe_base, step, block);
+    if ((E * D) % 4 != 0 || (size_t)E * D * sizeof(float) > 64 * 1024) VB_FAIL(VB_E_INVALID, "router: E*D=%d unsupported", E * D);
+    if (2 * E + 2 <= 16)
+        hipLaunchKernelGGL(router_kernel<4>, dim3(cdiv(N, 4 * RT_TPW)), dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
+                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, B > 0 ? B : 1, seed, clip_base, nfe_base, step, block);
+    else
+        hipLaunchKernelGGL(router_kernel<1>, dim3(cdiv(N, 4 * RT_TPW)), dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
+                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, B > 0 ? B : 1, seed, clip_base, nfe_base, step, block);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
@@ -470,21 +526,29 @@ __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restric
     __shared__ int wc[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = 2 * E;
-    if (tid < G) {
-        // group start = sum of all earlier groups' totals; + this group's tokens in earlier blocks
-        int before_groups = 0, before_blocks = 0;
-        for (int b = 0; b < nblk; ++b) {
-            for (int g = 0; g < tid; ++g) before_groups += counts[b * G + g];
-            if (b < (int)blockIdx.x) before_blocks += counts[b * G + tid];
+    // group start = sum of all earlier groups' totals; + this group's tokens in earlier blocks.  The counts table is
+    // summed by the whole block (thread = (row-of-counts, group)), not by G serial threads.
+    __shared__ int tot[32], bef[32];
+    if (tid < 32) { tot[tid] = 0; bef[tid] = 0; }
+    __syncthreads();
+    {
+        const int g = tid % G;
+        int t = 0, bf = 0;
+        for (int b = tid / G; b < nblk; b += BK_T / G) {
+            const int cnt = counts[b * G + g];
+            t += cnt;
+            if (b < (int)blockIdx.x) bf += cnt;
         }
-        base[tid] = before_groups + before_blocks;
+        if (tid < (BK_T / G) * G) { atomicAdd(&tot[g], t); atomicAdd(&bef[g], bf); }
+    }
+    __syncthreads();
+    if (tid < G) {
+        int before_groups = 0;
+        for (int g = 0; g < tid; ++g) before_groups += tot[g];
+        base[tid] = before_groups + bef[tid];
         if (blockIdx.x == 0) {
             group_off[tid] = before_groups;
-            if (tid == G - 1) {
-                int tot = 0;
-                for (int b = 0; b < nblk; ++b) tot += counts[b * G + tid];
-                group_off[G] = before_groups + tot;
-            }
+            if (tid == G - 1) group_off[G] = before_groups + tot[tid];
         }
     }
     const int n = blockIdx.x * BK_T + tid;

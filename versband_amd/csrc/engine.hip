@@ -397,7 +397,7 @@ static size_t net_ws_bytes(const NetProgram& n, int B, int T, std::vector<size_t
     if (offs) offs->clear();
     for (const vb_buf_desc& d : n.bufs) {
         size_t tl = (size_t)T * d.tmul;
-        size_t el = d.square ? tl * tl : (size_t)d.channels * tl;
+        size_t el = d.square == 1 ? tl * tl : (d.square == 2 ? (size_t)d.channels * ((tl + 31) / 32 * 32) : (size_t)d.channels * tl);
         if (offs) offs->push_back(off);
         off = align_up(off + el * B * sizeof(float));
     }
@@ -425,7 +425,7 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
         return n.bufs[id].channels;
     };
     auto bstride = [&](int id) -> int64_t {
-        if (id >= 0 && n.bufs[id].square) return (int64_t)tlen(id) * tlen(id);
+        if (id >= 0 && n.bufs[id].square == 1) return (int64_t)tlen(id) * tlen(id);
         return (int64_t)chans(id) * tlen(id);
     };
     for (size_t oi = 0; oi < n.ops.size(); ++oi) {
@@ -451,12 +451,21 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
             if (o.res != -1) { a.res = ptr(o.res); a.res_bstride = bstride(o.res); }
             a.alpha = o.alpha; a.beta = o.beta; a.acc_scale = o.acc_scale; a.out_act = o.out_act; a.out_slope = o.out_slope;
             a.out_transposed = o.out_transposed; a.B = B; a.tr_stride = o.tr_stride; a.tr_pad = o.tr_pad; a.tr_k = o.tr_k;
-            if (o.w_x3 && o.w_buf == -1) {
+            if (o.w_buf != -1 && o.ci_pad == -1) {
+                // per-batch split planes [2][B][Co][Ci_pad] written by an earlier VB_OP_SPLIT_PLANES
+                a.Ci_pad = (a.Ci + 31) / 32 * 32;
+                a.wp = reinterpret_cast<const bf16_t*>(ptr(o.w_buf)); a.wp_bstride = (int64_t)a.Co * a.Ci_pad;
+                a.wp_plane = (int64_t)B * a.wp_bstride; a.w = nullptr;
+            } else if (o.w_x3 && o.w_buf == -1) {
                 const int phases = o.tr_stride > 1 ? o.tr_stride : 1;
                 const int ntaps = o.tr_stride > 1 ? (o.tr_k + o.tr_stride - 1) / o.tr_stride : o.ksize;
                 a.wp = (const bf16_t*)o.w_x3; a.Ci_pad = o.ci_pad; a.wp_plane = (int64_t)phases * ntaps * a.Co * o.ci_pad;
             }
             VB_TRY(launch_conv1d(a, st));
+        } else if (o.kind == VB_OP_SPLIT_PLANES) {
+            const int rows = o.Co > 0 ? o.Co : tlen(o.x), cols = o.Ci > 0 ? o.Ci : tlen(o.x);
+            const int cpad = (cols + 31) / 32 * 32;
+            VB_TRY(launch_split_rows(ptr(o.x), (int64_t)B * rows, cols, cpad, reinterpret_cast<bf16_t*>(ptr(o.out)), (int64_t)B * rows * cpad, st));
         } else {
             VB_FAIL(VB_E_INVALID, "net op %zu: bad kind %d", oi, o.kind);
         }

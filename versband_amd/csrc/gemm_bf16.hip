@@ -34,6 +34,7 @@ struct GemmDev {
     const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
+    unsigned long long* trace;      // tuning only (vbdbg_gemm_trace): per block {t_start, t_loop_end, t_end, hw ids}
 };
 
 __device__ __forceinline__ void store4p(bf16_t* base, int64_t plane, int np, int64_t idx, const float v[4]) {
@@ -86,6 +87,9 @@ __device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok
 template <int EPI>
 __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int tok, float scale, int n, float v[4], const EpiPre& e) {
     // m: global row (slot) index, n: column within the group's [0,N), 4 consecutive columns, all < N
+    // The arithmetic is pinned (no implicit contraction, explicit fmaf): the launcher picks the tile configuration from the
+    // problem size, and a clip's result must not depend on the batch it rides in - every kernel variant has to round alike.
+#pragma clang fp contract(off)
     if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T) {
         v[0] += e.a.x; v[1] += e.a.y; v[2] += e.a.z; v[3] += e.a.w;
     }
@@ -99,8 +103,8 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_RESID_GATE) {
         const int col = g * p.c_noff_group + n;
-        float4 h = e.a;
-        h.x += e.b.x * v[0]; h.y += e.b.y * v[1]; h.z += e.b.z * v[2]; h.w += e.b.w * v[3];
+        float4 h;
+        h.x = fmaf(e.b.x, v[0], e.a.x); h.y = fmaf(e.b.y, v[1], e.a.y); h.z = fmaf(e.b.z, v[2], e.a.z); h.w = fmaf(e.b.w, v[3], e.a.w);
         *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + col) = h;
     } else if constexpr (EPI == EPI_SWIGLU) {
         float o0 = silu_f(v[0]) * v[1], o1 = silu_f(v[2]) * v[3];
@@ -116,7 +120,7 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
     } else if constexpr (EPI == EPI_SCATTER_F32) {
         *reinterpret_cast<float4*>(p.out32 + (int64_t)tok * p.ldc32 + n) = make_float4(scale * v[0], scale * v[1], scale * v[2], scale * v[3]);
     } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
-        float o[4] = {e.a.x + scale * v[0], e.a.y + scale * v[1], e.a.z + scale * v[2], e.a.w + scale * v[3]};
+        float o[4] = {fmaf(scale, v[0], e.a.x), fmaf(scale, v[1], e.a.y), fmaf(scale, v[2], e.a.z), fmaf(scale, v[3], e.a.w)};
         store4p(p.out, p.out_plane, p.out_np, (int64_t)tok * p.ldc + n, o);
     } else if constexpr (EPI == EPI_HEADS_T) {
         int b = m / p.T, t = m - b * p.T;
@@ -132,7 +136,7 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         int b = m / p.T, t = m - b * p.T;
         if (sec < 2) {
             const float c0 = e.a.x, c1 = e.a.y, s0 = e.a.z, s1 = e.a.w;
-            float o[4] = {v[0] * c0 - v[1] * s0, v[0] * s0 + v[1] * c0, v[2] * c1 - v[3] * s1, v[2] * s1 + v[3] * c1};
+            float o[4] = {fmaf(v[0], c0, -(v[1] * s0)), fmaf(v[0], s0, v[1] * c0), fmaf(v[2], c1, -(v[3] * s1)), fmaf(v[2], s1, v[3] * c1)};
             if (sec == 0) store4p(p.q, p.q_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
             else store4p(p.k, p.k_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
         } else {
@@ -309,13 +313,9 @@ template <int BKT> __device__ __forceinline__ int lds_off_t(int row, int c) {
     else return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) __builtin_amdgcn_s_waitcnt(0x0f70);
-    else if constexpr (N == 4) __builtin_amdgcn_s_waitcnt(0x0f74);
-    else if constexpr (N == 8) __builtin_amdgcn_s_waitcnt(0x0f78);
-    else if constexpr (N == 12) __builtin_amdgcn_s_waitcnt(0x0f7c);
-    else if constexpr (N == 16) __builtin_amdgcn_s_waitcnt(0x4f70);
-    else if constexpr (N == 24) __builtin_amdgcn_s_waitcnt(0x4f78);
-    else static_assert(N == 0, "unsupported vmcnt");
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    // s_waitcnt simm16 (gfx9): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; only vmcnt is counted here
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));
 }
 
 // ABL (tuning only): 1 = no tile DMA in the loop, 2 = no MFMA, 3 = no LDS fragment reads
@@ -332,6 +332,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
+    unsigned long long t_start = 0;
+    if constexpr (EPI == EPI_F32) { if (p.trace) t_start = __builtin_amdgcn_s_memtime(); }
 
     int g = 0, row0, rows_end, tile_n;
     {
@@ -410,34 +412,45 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
         if (ABL != 1 && t + NST - 1 < total) issue(t + NST - 1);
         const unsigned char* As = &lds[(st * 2 + 0) * OPB];
         const unsigned char* Bs = &lds[(st * 2 + 1) * OPB];
-#pragma unroll
-        for (int ks = 0; ks < BKT / 16; ++ks) {
-            bf16x8 af[2], bf[2];
+        // fragment reads are software-pipelined in registers: the ds_reads of k-step ks+1 are issued before the MFMAs of
+        // k-step ks (the compiler otherwise reuses one register set and serialises read -> wait -> 4 MFMA per k-step)
+        bf16x8 af[2][2], bf[2][2];
+        auto fload = [&](int ks, int slot) {
             const int c = ks * 2 + fk;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if constexpr (ABL == 3) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { af[i][e] = (bf16_t)(float)(t + e); bf[i][e] = (bf16_t)(float)(ks + e); }
+                    for (int e = 0; e < 8; ++e) { af[slot][i][e] = (bf16_t)(float)(t + e); bf[slot][i][e] = (bf16_t)(float)(ks + e); }
                 } else {
-                    af[i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
-                    bf[i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
+                    af[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
+                    bf[slot][i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
                 }
             }
+        };
+        fload(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < BKT / 16) fload(ks + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if constexpr (ABL == 2) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[i][j][e] += (float)af[i][e] * (float)bf[j][e];
+                        for (int e = 0; e < 8; ++e) acc[i][j][e] += (float)af[cur][i][e] * (float)bf[cur][j][e];
                     } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
                     }
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    unsigned long long t_loop = 0;
+    if constexpr (EPI == EPI_F32) { if (p.trace) t_loop = __builtin_amdgcn_s_memtime(); }
     if constexpr (ABL == 4) {
         float sink = 0.f;
 #pragma unroll
@@ -448,6 +461,278 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
     } else {
         wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
     }
+    if constexpr (EPI == EPI_F32) {
+        if (p.trace && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* tr = p.trace + (size_t)blockIdx.x * 4;
+            tr[0] = t_start; tr[1] = t_loop; tr[2] = __builtin_amdgcn_s_memtime(); tr[3] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+}
+
+
+// ---- variant 3: big block tiles, one workgroup per CU --------------------------------------------------------------
+// Per-block traces of the 128x128 kernel (tools/gemm_trace.py) show a k-iteration costs ~1500 cycles against 640 cycles
+// of MFMA: every iteration moves 32 KB through the CU's 64 B/clk vector-memory path (512 cycles at best) and waits for
+// the tile issued one iteration earlier, and a launch of M=12032 x N=768 leaves 2.2 tiles per CU (priced as 3).  This
+// kernel raises the flops per byte DMA'd and fits the tile grid to the 256 CUs instead:
+//   * block tile (64 TM) x (64 TN), 4 waves as 2x2, a wave owns (32 TM) x (32 TN) = TM x TN MFMA 32x32 tiles;
+//     192x192 (TM = TN = 3) moves 48 KB per 1440 MFMA cycles and makes 63 x 4 = 252 tiles of 12032 x 768;
+//   * BK = 64, NSTB-stage LDS ring filled by global_load_lds (same lane-linear image + source-side XOR swizzle as
+//     above), counted vmcnt waits: NSTB-1 tiles in flight;
+//   * fragment reads double-buffered in registers across the 4 k-steps of a tile;
+//   * epilogue staged through LDS (free after the loop): a slab of 64 rows x BN goes to LDS as fp32, is read back
+//     row-major so a lane owns 4 consecutive columns AND a wave covers whole 128-B lines - residual/bias loads and all
+//     stores become full-line transactions (the MFMA layout stores 32-B pieces of 32 different rows per instruction).
+// ABL (tuning only): 1 = no tile DMA inside the loop, 2 = no MFMA, 3 = no fragment reads
+template <int EPI, int TM, int TN, int NSTB, int ABL = 0>
+__global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p) {
+    constexpr int BMB = 64 * TM, BNB = 64 * TN;
+    constexpr int PA = BMB / 32, PB = BNB / 32;        // 1-KB DMA pieces (8 tile rows) per wave per tile
+    constexpr int LPT = PA + PB;
+    constexpr int ABYTES = BMB * 128, BBYTES = BNB * 128, STAGE = ABYTES + BBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    if constexpr (EPI == EPI_F32) { if (p.trace) t_start = __builtin_amdgcn_s_memtime(); }
+
+    int g = 0, row0, rows_end, tile_n;
+    {
+        const int L = blockIdx.x, nN = p.n_tiles;
+        const int jx = L >> 3;
+        tile_n = jx % nN;
+        int tmg = (jx / nN) * 8 + (L & 7);
+        if (p.group_off) {
+            bool found = false;
+            for (int gi = 0; gi < p.ngroups; ++gi) {
+                int lo = p.group_off[gi], hi = p.group_off[gi + 1];
+                int nt = (hi - lo + BMB - 1) / BMB;
+                if (tmg < nt) { g = gi; row0 = lo + tmg * BMB; rows_end = hi; found = true; break; }
+                tmg -= nt;
+            }
+            if (!found) return;
+        } else {
+            g = blockIdx.z;
+            row0 = tmg * BMB; rows_end = p.M;
+            if (row0 >= rows_end) return;
+        }
+    }
+    const int n0 = tile_n * BNB;
+    const int KT = p.K / 64;
+    const int total = KT * p.nseg;
+
+    const bf16_t* asrc[PA]; const bf16_t* bsrc[PB];
+    {
+        const int r8 = lane >> 3, cs = lane & 7;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = 8 * (wave * PA + i) + r8;
+            const int c = cs ^ ((r >> 1) & 7);
+            int slot = row0 + r;
+            if (slot >= rows_end) slot = row0;
+            const int arow = p.a_rows ? p.a_rows[slot] : slot;
+            asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int r = 8 * (wave * PB + i) + r8;
+            const int c = cs ^ ((r >> 1) & 7);
+            int nrow = n0 + r;
+            if (nrow >= p.N) nrow = 0;
+            bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
+        }
+    }
+    auto issue = [&](int t) {
+        const int st = t % NSTB;
+        const int seg = t / KT;
+        const int k0 = (t - seg * KT) * 64;
+        const int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
+        const int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+        unsigned char* sa = ldsb + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ao), (lds_ptr_t)(sa + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + bo), (lds_ptr_t)(sa + ABYTES + (wave * PB + i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Software pipeline across tiles (NSTB = 3 stages, 2 tiles of DMA in flight):
+    //   a tile's LAST fragment set (k-step 3) is read into registers during k-step 2, so its stage is dead at the
+    //   "boundary" inside iteration t: [lgkmcnt(0)] [tile t+1 landed] [barrier] -> read k-step 0 of tile t+1, queue the
+    //   k-step-3 MFMAs of tile t, and refill stage t%3 with tile t+3 while they run.  LDS latency, the barrier and the DMA
+    //   issue of a tile boundary all sit in the shadow of 9 MFMAs instead of in front of them.
+    static_assert(NSTB == 3, "pipeline written for a 3-stage ring");
+#pragma unroll
+    for (int t = 0; t < NSTB; ++t)
+        if (t < total) issue(t);
+    const int frow = lane & 31, fk = lane >> 5;
+    bf16x8 af[2][TM], bf[2][TN];
+    auto fload = [&](int st, int ks, int slot) {
+        const unsigned char* As = ldsb + st * STAGE;
+        const unsigned char* Bs = As + ABYTES;
+        const int c = ks * 2 + fk;
+        if constexpr (ABL == 3) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[slot][i][e] = (bf16_t)(float)(st + e + i);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[slot][j][e] = (bf16_t)(float)(ks + e + j);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<64>(wr * 32 * TM + i * 32 + frow, c));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<64>(wc * 32 * TN + j * 32 + frow, c));
+    };
+    auto mfmas = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (ABL == 2) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[i][j][e] += (float)af[slot][i][e] * (float)bf[slot][j][e];
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[slot][j], af[slot][i], acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+    if (total > 2) wait_vmcnt<2 * LPT>();
+    else if (total > 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (total > 0) fload(0, 0, 0);
+    if constexpr (EPI == EPI_F32) { if (p.trace) t_pro = __builtin_amdgcn_s_memtime(); }
+    int st = 0;
+    for (int t = 0; t < total; ++t) {
+        // k-steps 0..2 (fragments of k-step ks+1 are requested before the MFMAs of ks are queued)
+        fload(st, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(st, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        fload(st, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // boundary
+        const int nst = st == NSTB - 1 ? 0 : st + 1;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): k-step 3 fragments are in registers -> stage st is dead
+        if (t + 1 < total) {
+            if (t + 2 < total) wait_vmcnt<LPT>(); else wait_vmcnt<0>();     // tile t+1 landed (tile t+2 may stay in flight)
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < total) fload(nst, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 1 && t + NSTB < total) issue(t + NSTB);               // refills stage st
+        st = nst;
+    }
+
+    if constexpr (EPI == EPI_F32) { if (p.trace) t_loop = __builtin_amdgcn_s_memtime(); }
+    // ---- epilogue through LDS, one 64-row slab (32 rows of each wave row) at a time
+    constexpr int PITCH = BNB + 4;               // floats; +4 keeps the 16-B column writes of 8 consecutive rows on distinct banks
+    constexpr int QPR = BNB / 4;                 // quads per row
+    constexpr int QPT = 64 * QPR / NTHREADS;     // quads per thread per slab
+    float* stg = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): own LDS reads done (loop fragments / previous slab)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = wc * 32 * TN + j * 32 + q * 8 + fk * 4;
+                *reinterpret_cast<float4*>(stg + (wr * 32 + frow) * PITCH + col) =
+                    make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        EpiPre pre[QPT];
+        int slot_[QPT], tok_[QPT]; float scale_[QPT];
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int idx = tid + k * NTHREADS;
+            const int lr = idx / QPR, cq = idx - lr * QPR;
+            const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
+            const int n = n0 + cq * 4;
+            slot_[k] = (slot < rows_end && n < p.N) ? slot : -1;
+            tok_[k] = slot; scale_[k] = 1.f;
+            if (slot_[k] >= 0) {
+                if constexpr (EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES) {
+                    tok_[k] = p.rows_out[slot];
+                    scale_[k] = p.row_scale[tok_[k]];
+                }
+                epi_load<EPI>(p, g, slot, tok_[k], n, pre[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            if (slot_[k] < 0) continue;
+            const int idx = tid + k * NTHREADS;
+            const int lr = idx / QPR, cq = idx - lr * QPR;
+            const float4 vv = *reinterpret_cast<const float4*>(stg + lr * PITCH + cq * 4);
+            float v[4] = {vv.x, vv.y, vv.z, vv.w};
+            epi_store<EPI>(p, g, slot_[k], tok_[k], scale_[k], n0 + cq * 4, v, pre[k]);
+        }
+    }
+    if constexpr (EPI == EPI_F32) {
+        if (p.trace && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* tr = p.trace + (size_t)blockIdx.x * 4;
+            tr[0] = t_start; tr[1] = t_loop; tr[2] = __builtin_amdgcn_s_memtime();
+            tr[3] = ((unsigned long long)(t_pro - t_start) << 36) | ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+}
+
+template <int EPI, int TM, int TN, int NSTB>
+static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)NSTB * (64 * TM + 64 * TN) * 128;
+    if constexpr (EPI == EPI_F32 && TM == 3 && TN == 3) {
+        const char* ea = getenv("VB_GEMM_ABLATE");
+        const int abl = ea ? atoi(ea) : 0;
+        if (abl >= 1 && abl <= 3) {
+            auto k = abl == 1 ? gemm_bf16_big_kernel<EPI, TM, TN, NSTB, 1> : (abl == 2 ? gemm_bf16_big_kernel<EPI, TM, TN, NSTB, 2> : gemm_bf16_big_kernel<EPI, TM, TN, NSTB, 3>);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(NTHREADS), lds, st, d);
+            return;
+        }
+    }
+    static_assert(lds >= (size_t)64 * (64 * TN + 4) * 4, "epilogue staging slab must fit in the ring");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), grid, dim3(NTHREADS), lds, st, d);
 }
 
 template <int EPI>
@@ -472,6 +757,9 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
 }
 
+static unsigned long long* g_gemm_trace = nullptr;
+extern "C" void vbdbg_gemm_trace(void* buf) { g_gemm_trace = static_cast<unsigned long long*>(buf); }   // tuning tool hook, not ABI
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return VB_OK;
     if (a.N % 4 || a.K % 8 || a.lda % 8 || a.ldb % 8) VB_FAIL(VB_E_INVALID, "gemm: N%%4, K%%8, lda%%8, ldb%%8 must be 0 (N=%d K=%d)", a.N, a.K);
@@ -487,22 +775,51 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
     d.qkv_np = a.q.np; d.rope_cos = a.rope_cos; d.rope_sin = a.rope_sin; d.H = a.H; d.hd = a.hd > 0 ? a.hd : 1;
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
+    d.trace = g_gemm_trace;
     ProfScope prof(0, 2.0 * a.M * a.N * a.K * ((a.group_off || a.ngroups <= 1) ? 1 : a.ngroups), st);
-    int mt = a.group_off ? (cdiv(a.M, BM) + a.ngroups) : cdiv(a.M, BM);
-    d.n_tiles = cdiv(a.N, BN);
+    // tile configuration: 0 = 128x128 (two workgroups per CU), else (TM, TN) of the big-tile kernel (one per CU).  The
+    // big tiles are taken when K allows the DMA ring; among them the one that wastes the fewest tile-slots of the last
+    // round of 256 CUs and of partial edge tiles wins.  VB_GEMM_TILE=22|33|24|42 overrides (tuning).
+    int cfg = 0;
+    if (a.K % 64 == 0) {
+        const char* et = getenv("VB_GEMM_TILE");
+        const int forced = et ? atoi(et) : -1;
+        if (forced >= 0) cfg = forced == 22 ? 0 : forced;
+        else {
+            // measured (tools/gemm_tilecfg.py): the 192x192 kernel wins when its tiles fit one round of the 256 CUs
+            // (12032 x 768: 252 tiles); with several rounds per CU the 128x128 kernel (two co-resident workgroups
+            // overlapping each other's epilogue) is as fast or faster.
+            const int gz = a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
+            const int64_t rt = a.group_off ? (cdiv(a.M, 192) + a.ngroups) : cdiv(a.M, 192);
+            const int64_t t33 = rt * cdiv(a.N, 192) * gz;
+            const int64_t t22 = (a.group_off ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
+            if (t33 <= 256 + 16 && t22 > 320) cfg = 33;
+        }
+    }
+    const int bm = cfg ? 64 * (cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10) : BN;
+    int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
+    d.n_tiles = cdiv(a.N, bn);
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
+#define VB_GEMM_CASE(E) \
+        case E: \
+            if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
+            else if (cfg == 24) launch_big<E, 2, 4, 3>(d, grid, st); \
+            else if (cfg == 42) launch_big<E, 4, 2, 3>(d, grid, st); \
+            else launch_t<E>(d, grid, st); \
+            break;
     switch (a.epi) {
-        case EPI_PLANES: launch_t<EPI_PLANES>(d, grid, st); break;
-        case EPI_F32: launch_t<EPI_F32>(d, grid, st); break;
-        case EPI_QKV_ROPE: launch_t<EPI_QKV_ROPE>(d, grid, st); break;
-        case EPI_RESID_GATE: launch_t<EPI_RESID_GATE>(d, grid, st); break;
-        case EPI_SWIGLU: launch_t<EPI_SWIGLU>(d, grid, st); break;
-        case EPI_SCATTER_F32: launch_t<EPI_SCATTER_F32>(d, grid, st); break;
-        case EPI_SCATTER_ADD_PLANES: launch_t<EPI_SCATTER_ADD_PLANES>(d, grid, st); break;
-        case EPI_GELU_PLANES: launch_t<EPI_GELU_PLANES>(d, grid, st); break;
-        case EPI_HEADS_T: launch_t<EPI_HEADS_T>(d, grid, st); break;
+        VB_GEMM_CASE(EPI_PLANES)
+        VB_GEMM_CASE(EPI_F32)
+        VB_GEMM_CASE(EPI_QKV_ROPE)
+        VB_GEMM_CASE(EPI_RESID_GATE)
+        VB_GEMM_CASE(EPI_SWIGLU)
+        VB_GEMM_CASE(EPI_SCATTER_F32)
+        VB_GEMM_CASE(EPI_SCATTER_ADD_PLANES)
+        VB_GEMM_CASE(EPI_GELU_PLANES)
+        VB_GEMM_CASE(EPI_HEADS_T)
         default: VB_FAIL(VB_E_INVALID, "gemm: bad epilogue %d", a.epi);
     }
+#undef VB_GEMM_CASE
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

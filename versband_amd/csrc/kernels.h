@@ -84,6 +84,7 @@ struct ConvArgs {
     int tr_stride = 1; int tr_pad = 0; int tr_k = 0;
     // optional split-bf16 weights [2][phase][tap][Co][Ci_pad] (Ci_pad % 32 == 0): selects the bf16x3 MFMA kernel
     const bf16_t* wp = nullptr; int64_t wp_plane = 0; int Ci_pad = 0;
+    int64_t wp_bstride = 0;          // per-batch split weights (bf16 elements inside a plane), VAE attention
 };
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
 
@@ -95,6 +96,8 @@ int launch_rmsnorm_mod(const float* h, const float* w, const float* shift, const
 int launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps, float* out32, Planes outp,
                      hipStream_t st);
 int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st);
+// f32 [rows][cols] -> split-bf16 planes [2][rows][cpad] (cpad % 4 == 0, columns >= cols zero filled)
+int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st);
 int launch_planes_to_f32(Planes in, int64_t n, float* out, hipStream_t st);
 int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias,
                      int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st);

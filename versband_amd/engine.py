@@ -191,15 +191,19 @@ class NetBuilder:
         self.ops.append(op)
         return st
 
+    def split_planes(self, x: int, out: int, rows: int, cols: int):
+        """f32 [B][rows][cols] buffer -> split-bf16 planes [2][B][rows][roundup(cols,32)] (-1 = the buffer's time length)."""
+        self.ops.append(L.NetOp(kind=L.OP_SPLIT_PLANES, x=x, out=out, res=-1, stats=-1, w_buf=-1, Ci=cols, Co=rows))
+
     def softmax_t(self, x: int, out: int):
         self.ops.append(L.NetOp(kind=L.OP_SOFTMAX_T, x=x, out=out, res=-1, stats=-1, w_buf=-1))
 
     def conv(self, x: int, out: int, Ci: int, Co: int, w: Optional[Tensor] = None, bias: Optional[Tensor] = None, k: int = 1,
              dil: int = 1, pad: int = 0, res: int = -1, stats: int = -1, gamma=None, beta_gn=None, in_act=L.ACT_NONE,
              in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
-             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32):
-        w_x3, ci_pad = None, 0
-        if self.precision == "split" and w is not None and w_buf == -1 and not out_transposed:
+             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32, w_buf_planes=False):
+        w_x3, ci_pad = None, (-1 if w_buf_planes else 0)
+        if self.precision == "split" and w is not None and w_buf == -1:
             planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
             self.keep.append(planes)
             w_x3 = planes.data_ptr()
@@ -275,22 +279,37 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
         return out, cout
 
     def attnblock(x, c, tm, p):
+        # single-head attention over time (AttnBlock1D, autoencoder1d.py): both matrix products run as k=1 convs whose
+        # "weights" are per-batch activations.  split mode: those activations are split into bf16 hi/lo planes on the
+        # device (q as [T][C], v as [C][T padded to 32]) so the bf16x3 MFMA kernel does the products too.
         st = nb.gn_stats(x, c)
-        q, k, vT = nb.buf(c, tm), nb.buf(c, tm), nb.buf(c, tm)
+        split = nb.precision == "split"
+        q, k, v = nb.buf(c, tm), nb.buf(c, tm), nb.buf(c, tm)
         gam, bet = g[p + "norm.weight"], g[p + "norm.bias"]
-        for name, dst, tr in (("q", q, 0), ("k", k, 0), ("v", vT, 1)):
+        for name, dst, tr in (("q", q, 1 if split else 0), ("k", k, 0), ("v", v, 0 if split else 1)):
             w, b = cw(p + name)
             nb.conv(x, dst, c, c, w, b, stats=st, gamma=gam, beta_gn=bet, in_act=L.ACT_GN, out_transposed=tr)
         s = nb.buf(0, tm, True)
-        nb.conv(k, s, c, -1, w_buf=q, acc_scale=float(int(c) ** (-0.5)))      # w[b,i,j] = sum_c q[c,i] k[c,j] * C^-0.5
+        tmp = []
+        if split:
+            qp, vp = nb.buf(c, tm), nb.buf(c, tm, 2)
+            nb.split_planes(q, qp, rows=-1, cols=c)                            # q^T [T][C] -> planes
+            nb.split_planes(v, vp, rows=c, cols=-1)                            # v [C][T] -> planes, T padded
+            tmp = [qp, vp]
+            nb.conv(k, s, c, -1, w_buf=qp, w_buf_planes=True, acc_scale=float(int(c) ** (-0.5)))
+        else:
+            nb.conv(k, s, c, -1, w_buf=q, acc_scale=float(int(c) ** (-0.5)))  # w[b,i,j] = sum_c q[c,i] k[c,j] * C^-0.5
         pT = nb.buf(0, tm, True)
         nb.softmax_t(s, pT)
         a = nb.buf(c, tm)
-        nb.conv(pT, a, -1, c, w_buf=vT)                                        # h[c,i] = sum_j v[c,j] P[i,j]
+        if split:
+            nb.conv(pT, a, -1, c, w_buf=vp, w_buf_planes=True)
+        else:
+            nb.conv(pT, a, -1, c, w_buf=v)                                     # h[c,i] = sum_j v^T[j,c] P[i,j]
         out = nb.buf(c, tm)
         w, b = cw(p + "proj_out")
         nb.conv(a, out, c, c, w, b, res=x)
-        for t in (st, q, k, vT, s, pT, a, x):
+        for t in [st, q, k, v, s, pT, a, x] + tmp:
             nb.release(t)
         return out
 
