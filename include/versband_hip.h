@@ -156,7 +156,10 @@ typedef struct { int channels; int tmul; int square; } vb_buf_desc;   /* square:
 /* VB_OP_SPLIT_PLANES: x (f32 [B][rows][cols], rows = Co, cols = Ci, -1 = the buffer's time length) -> out = split-bf16
  * planes [2][B][rows][roundup(cols, 32)]; a later VB_OP_CONV with w_buf = that buffer and ci_pad = -1 uses them as
  * per-batch weights on the bf16x3 kernel (the VAE decoder's single-head attention) */
-enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3 };
+/* VB_OP_RESPAIR: fused HiFi-GAN ResBlock1 pair (vocoder/hifigan/modules/hifigan.py ResBlock1.forward), Ci = Co = 32 or 64:
+ * out = beta*out + alpha*(x + bias2 + conv2_k( lrelu( bias + conv1_{k,dil}( lrelu(x) ) ) )), w_x3 / w2_x3 split planes */
+/* VB_OP_GN_APPLY: out = GroupNorm affine of x from `stats` (+ swish when in_act == VB_ACT_GN_SWISH), same layout */
+enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3, VB_OP_RESPAIR = 4, VB_OP_GN_APPLY = 5 };
 enum { VB_ACT_NONE = 0, VB_ACT_LRELU = 1, VB_ACT_GN_SWISH = 2, VB_ACT_TANH = 3, VB_ACT_GN = 4 };
 #define VB_BUF_INPUT (-2)
 #define VB_BUF_OUTPUT (-3)
@@ -167,6 +170,7 @@ typedef struct {
     int Ci, Co, ksize, dil, pad, upsample2, in_act, out_act, out_transposed, tr_stride, tr_pad, tr_k, gn_groups;
     float in_slope, out_slope, alpha, beta, acc_scale;
     const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
+    const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution */
 } vb_net_op;
 
 enum { VB_NET_VAE = 0, VB_NET_VOCODER = 1 };

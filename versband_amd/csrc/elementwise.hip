@@ -686,6 +686,44 @@ int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, 
     return VB_OK;
 }
 
+// GroupNorm affine (+ swish) applied once, for the wide VAE layers: the conv kernels can fuse it into their staging, but a
+// layer with Co/128 output-channel tiles would then redo the exp/div of every input element Co/128 times
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int C, int T, int groups, int swish, float* out) {
+    const int row = blockIdx.y;                 // b * C + c
+    const int b = row / C, c = row - b * C;
+    const int grp = c / (C / groups);
+    const float rs = rstd[b * groups + grp] * gamma[c];
+    const float sh = beta[c] - mean[b * groups + grp] * rs;
+    const float* xr = x + (int64_t)row * T;
+    float* orow = out + (int64_t)row * T;
+    for (int t = (blockIdx.x * 256 + threadIdx.x) * 4; t < T; t += gridDim.x * 1024) {
+        if (t + 3 < T && (T & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + t);
+            float o[4] = {v.x * rs + sh, v.y * rs + sh, v.z * rs + sh, v.w * rs + sh};
+            if (swish) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + __expf(-o[k]));
+            }
+            *reinterpret_cast<float4*>(orow + t) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int k = t; k < min(t + 4, T); ++k) {
+                float o = xr[k] * rs + sh;
+                if (swish) o = o / (1.f + __expf(-o));
+                orow[k] = o;
+            }
+        }
+    }
+}
+int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
+                    int groups, int swish, float* out, hipStream_t st) {
+    if (C % groups) VB_FAIL(VB_E_INVALID, "gn_apply: C %% groups");
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(T, 1024), B * C), dim3(256), 0, st, x, mean, rstd, gamma, beta, C, T, groups, swish, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // softmax over the last dim of s[B][R][Cc], written transposed: out_t[b][c][r]
 __global__ void __launch_bounds__(256) softmax_rows_t_kernel(const float* __restrict__ s, int R, int Cc, float* out_t) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);

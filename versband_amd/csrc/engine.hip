@@ -462,6 +462,17 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
                 a.wp = (const bf16_t*)o.w_x3; a.Ci_pad = o.ci_pad; a.wp_plane = (int64_t)phases * ntaps * a.Co * o.ci_pad;
             }
             VB_TRY(launch_conv1d(a, st));
+        } else if (o.kind == VB_OP_GN_APPLY) {
+            float* stp = ptr(o.stats);
+            VB_TRY(launch_gn_apply(ptr(o.x), stp, stp + (size_t)B * o.gn_groups, o.gn_gamma, o.gn_beta, B, o.Ci, tlen(o.x), o.gn_groups,
+                                   o.in_act == ACT_GN_SWISH ? 1 : 0, ptr(o.out), st));
+        } else if (o.kind == VB_OP_RESPAIR) {
+            RespairArgs r;
+            r.x = ptr(o.x); r.out = ptr(o.out); r.B = B; r.C = o.Ci; r.T = tlen(o.x); r.k = o.ksize; r.dil = o.dil;
+            r.w1 = (const bf16_t*)o.w_x3; r.w2 = (const bf16_t*)o.w2_x3; r.b1 = o.bias; r.b2 = o.bias2;
+            r.slope = o.in_slope; r.alpha = o.alpha; r.beta = o.beta;
+            if (!r.w1 || !r.w2 || !r.b1 || !r.b2 || tlen(o.out) != r.T) VB_FAIL(VB_E_INVALID, "net op %zu: incomplete respair", oi);
+            VB_TRY(launch_respair(r, st));
         } else if (o.kind == VB_OP_SPLIT_PLANES) {
             const int rows = o.Co > 0 ? o.Co : tlen(o.x), cols = o.Ci > 0 ? o.Ci : tlen(o.x);
             const int cpad = (cols + 31) / 32 * 32;

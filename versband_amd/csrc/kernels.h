@@ -87,6 +87,14 @@ struct ConvArgs {
     int64_t wp_bstride = 0;          // per-batch split weights (bf16 elements inside a plane), VAE attention
 };
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
+// fused HiFi-GAN ResBlock1 pair (respair_x3.hip): out = beta*out + alpha*(x + b2 + conv2(lrelu(b1 + conv1_dil(lrelu(x)))))
+struct RespairArgs {
+    const float* x = nullptr; float* out = nullptr; int B = 1, C = 0, T = 0, k = 3, dil = 1;
+    const bf16_t* w1 = nullptr; const bf16_t* w2 = nullptr;     // split planes [2][k][C][C]
+    const float* b1 = nullptr; const float* b2 = nullptr;
+    float slope = 0.1f, alpha = 1.f, beta = 0.f;
+};
+int launch_respair(const RespairArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // small kernels
@@ -97,6 +105,8 @@ int launch_layernorm(const float* x, const float* w, const float* b, int rows, i
                      hipStream_t st);
 int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st);
 // f32 [rows][cols] -> split-bf16 planes [2][rows][cpad] (cpad % 4 == 0, columns >= cols zero filled)
+int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
+                    int groups, int swish, float* out, hipStream_t st);
 int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st);
 int launch_planes_to_f32(Planes in, int64_t n, float* out, hipStream_t st);
 int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias,

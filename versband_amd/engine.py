@@ -195,6 +195,17 @@ class NetBuilder:
         """f32 [B][rows][cols] buffer -> split-bf16 planes [2][B][rows][roundup(cols,32)] (-1 = the buffer's time length)."""
         self.ops.append(L.NetOp(kind=L.OP_SPLIT_PLANES, x=x, out=out, res=-1, stats=-1, w_buf=-1, Ci=cols, Co=rows))
 
+    def respair(self, x: int, out: int, ch: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, k: int, dil: int, slope: float,
+                alpha: float, beta: float):
+        """Fused HiFi-GAN ResBlock1 pair (w1/w2 fp32 packed [k][Ci][Co]); narrow stages only (ch = 32 or 64)."""
+        p1, c1 = pack.pack_conv_x3(w1.to(self.device))
+        p2, c2 = pack.pack_conv_x3(w2.to(self.device))
+        assert c1 == ch and c2 == ch
+        self.keep += [p1, p2]
+        self.ops.append(L.NetOp(kind=L.OP_RESPAIR, x=x, out=out, res=-1, stats=-1, w_buf=-1, bias=self._t(b1), bias2=self._t(b2),
+                                Ci=ch, Co=ch, ksize=k, dil=dil, in_slope=slope, alpha=alpha, beta=beta, w_x3=p1.data_ptr(),
+                                w2_x3=p2.data_ptr(), ci_pad=ch))
+
     def softmax_t(self, x: int, out: int):
         self.ops.append(L.NetOp(kind=L.OP_SOFTMAX_T, x=x, out=out, res=-1, stats=-1, w_buf=-1))
 
@@ -203,6 +214,12 @@ class NetBuilder:
              in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
              acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32, w_buf_planes=False):
         w_x3, ci_pad = None, (-1 if w_buf_planes else 0)
+        tmp = -1
+        if (self.precision == "split" and in_act in (L.ACT_GN_SWISH, L.ACT_GN) and stats >= 0 and x >= 0 and Co >= self.GN_PREPASS_MIN_CO
+                and not upsample2):
+            # wide layer: apply the norm (+swish) once instead of once per 128-wide output-channel tile
+            tmp = self.gn_apply(x, Ci, stats, gamma, beta_gn, in_act, groups)
+            x, stats, gamma, beta_gn, in_act = tmp, -1, None, None, L.ACT_NONE
         if self.precision == "split" and w is not None and w_buf == -1:
             planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
             self.keep.append(planes)
@@ -213,6 +230,16 @@ class NetBuilder:
                      tr_pad=tr_pad, tr_k=tr_k, gn_groups=groups, in_slope=in_slope, out_slope=out_slope, alpha=alpha, beta=beta,
                      acc_scale=acc_scale, w_x3=w_x3, ci_pad=ci_pad)
         self.ops.append(op)
+        self.release(tmp)
+
+    GN_PREPASS_MIN_CO = 512
+
+    def gn_apply(self, x: int, channels: int, stats: int, gamma, beta_gn, act: int, groups: int = 32) -> int:
+        """x -> new buffer holding GroupNorm(x) (act = ACT_GN) or swish(GroupNorm(x)) (ACT_GN_SWISH)."""
+        out = self.buf(channels, self.bufs[x][1])
+        self.ops.append(L.NetOp(kind=L.OP_GN_APPLY, x=x, out=out, res=-1, stats=stats, w_buf=-1, gn_gamma=self._t(gamma),
+                                gn_beta=self._t(beta_gn), Ci=channels, gn_groups=groups, in_act=act))
+        return out
 
 
 class ConvNet:
@@ -286,9 +313,14 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
         split = nb.precision == "split"
         q, k, v = nb.buf(c, tm), nb.buf(c, tm), nb.buf(c, tm)
         gam, bet = g[p + "norm.weight"], g[p + "norm.bias"]
+        xn = nb.gn_apply(x, c, st, gam, bet, L.ACT_GN) if (split and c >= nb.GN_PREPASS_MIN_CO) else -1
         for name, dst, tr in (("q", q, 1 if split else 0), ("k", k, 0), ("v", v, 0 if split else 1)):
             w, b = cw(p + name)
-            nb.conv(x, dst, c, c, w, b, stats=st, gamma=gam, beta_gn=bet, in_act=L.ACT_GN, out_transposed=tr)
+            if xn >= 0:
+                nb.conv(xn, dst, c, c, w, b, out_transposed=tr)
+            else:
+                nb.conv(x, dst, c, c, w, b, stats=st, gamma=gam, beta_gn=bet, in_act=L.ACT_GN, out_transposed=tr)
+        nb.release(xn)
         s = nb.buf(0, tm, True)
         tmp = []
         if split:
@@ -348,7 +380,7 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
     return ConvNet(ctx, L.NET_VAE, nb, zc, co, tm)
 
 
-def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split") -> ConvNet:
+def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split", fuse_pairs: Sequence[int] = (32,)) -> ConvNet:
     """HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) as an op list; fully
     driven by the vocoder's config.yaml keys."""
     nb = NetBuilder(ctx.device, precision)
@@ -379,7 +411,13 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
                 last = m == len(rd) - 1
                 dst = xs if last else nb.buf(ch, tm)
                 al, be = (1.0 / nk, 0.0 if j == 0 else 1.0) if last else (1.0, 0.0)
-                if hp["resblock"] == "1":
+                if hp["resblock"] == "1" and precision == "split" and ch in fuse_pairs and (rk - 1) * d <= 64 and rk % 2 == 1:
+                    # narrowest, longest stage: both convolutions of the pair in one launch, intermediate kept in LDS
+                    # (measured: 645 us per pair against 2 x 600 us at 32 channels; at 64 channels the fused kernel
+                    #  fits one workgroup per CU only and loses, 1525 us against 2 x 640 us - so it is not used there)
+                    nb.respair(r, dst, ch, pack.pack_conv(wt(f"resblocks.{n}.convs1.{m}")), sd[f"resblocks.{n}.convs1.{m}.bias"],
+                               pack.pack_conv(wt(f"resblocks.{n}.convs2.{m}")), sd[f"resblocks.{n}.convs2.{m}.bias"], rk, d, 0.1, al, be)
+                elif hp["resblock"] == "1":
                     t1 = nb.buf(ch, tm)
                     nb.conv(r, t1, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs1.{m}")), sd[f"resblocks.{n}.convs1.{m}.bias"], k=rk,
                             dil=d, pad=(rk * d - d) // 2, in_act=L.ACT_LRELU, in_slope=0.1)
