@@ -652,36 +652,54 @@ int launch_rows_dot(const float* x, const float* W, const float* bias, int N, in
 // GroupNorm statistics (autoencoder1d.py:165-166): one block per (b, group); the group's
 // channels are contiguous in [B][C][T].  Two-pass mean / biased variance.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int C, int T, int groups, float eps, float* mean,
-                                                      float* rstd) {
-    __shared__ float red[4];
+#define GS_T 1024
+__global__ void __launch_bounds__(GS_T) gn_stats_kernel(const float* __restrict__ x, int C, int T, int groups, float eps, float* mean,
+                                                       float* rstd) {
+    __shared__ float red[GS_T / 64];
     __shared__ float s_mean;
     const int bg = blockIdx.x;
     const int64_t n = (int64_t)(C / groups) * T;
     const float* p = x + (int64_t)bg * n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    const int64_t n4 = vec ? n / 4 : 0;
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += p[i];
+    for (int64_t i = threadIdx.x; i < n4; i += GS_T) {
+        const float4 v = reinterpret_cast<const float4*>(p)[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += GS_T) s += p[i];
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    if (threadIdx.x == 0) s_mean = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < GS_T / 64; ++w) t += red[w];
+        s_mean = t / (float)n;
+    }
     __syncthreads();
     const float m = s_mean;
     float v = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) { float d = p[i] - m; v += d * d; }
+    for (int64_t i = threadIdx.x; i < n4; i += GS_T) {
+        const float4 q = reinterpret_cast<const float4*>(p)[i];
+        const float d0 = q.x - m, d1 = q.y - m, d2 = q.z - m, d3 = q.w - m;
+        v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += GS_T) { float d = p[i] - m; v += d * d; }
     v = wave_sum(v);
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < GS_T / 64; ++w) t += red[w];
         mean[bg] = m;
-        rstd[bg] = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)n + eps);
+        rstd[bg] = rsqrtf(t / (float)n + eps);
     }
 }
 int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, float* mean, float* rstd, hipStream_t st) {
     if (C % groups) VB_FAIL(VB_E_INVALID, "gn_stats: C%%groups");
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, st, x, C, T, groups, eps, mean, rstd);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(GS_T), 0, st, x, C, T, groups, eps, mean, rstd);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

@@ -34,8 +34,13 @@ struct GemmDev {
     const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
+    float rT, rhd, rD;              // reciprocals for fdiv(): the epilogues decompose row -> (clip, t) and column -> (head, d)
     unsigned long long* trace;      // tuning only (vbdbg_gemm_trace): per block {t_start, t_loop_end, t_end, hw ids}
 };
+
+// x / d for 0 <= x < 2^21 without the ~40-instruction integer division: (x + 0.5) / d is at least 0.5/d away
+// from every integer, far more than the fp32 rounding of the product.  rinv = 1.0f / d.
+__device__ __forceinline__ int fdiv(int x, float rinv) { return (int)(((float)x + 0.5f) * rinv); }
 
 __device__ __forceinline__ void store4p(bf16_t* base, int64_t plane, int np, int64_t idx, const float v[4]) {
     bf16x4 hi;
@@ -70,13 +75,13 @@ __device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok
     } else if constexpr (EPI == EPI_RESID_GATE) {
         const int col = g * p.c_noff_group + n;
         e.a = *reinterpret_cast<const float4*>(p.out32 + (int64_t)m * p.ldc32 + col);
-        e.b = *reinterpret_cast<const float4*>(p.gate + (int64_t)(m / p.T) * p.gate_ld + col);
+        e.b = *reinterpret_cast<const float4*>(p.gate + (int64_t)fdiv(m, p.rT) * p.gate_ld + col);
     } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
         e.a = *reinterpret_cast<const float4*>(p.y32_in + (int64_t)tok * p.ldc32 + n);
     } else if constexpr (EPI == EPI_QKV_ROPE) {
         if (n < 2 * p.D) {
-            const int nn = n % p.D, t = m % p.T;
-            const int jd = (nn % p.hd) >> 1;
+            const int nn = n - fdiv(n, p.rD) * p.D, t = m - fdiv(m, p.rT) * p.T;
+            const int jd = (nn - fdiv(nn, p.rhd) * p.hd) >> 1;
             const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (int64_t)t * (p.hd / 2) + jd);
             const float2 sn = *reinterpret_cast<const float2*>(p.rope_sin + (int64_t)t * (p.hd / 2) + jd);
             e.a = make_float4(cs.x, cs.y, sn.x, sn.y);
@@ -123,17 +128,17 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         float o[4] = {fmaf(scale, v[0], e.a.x), fmaf(scale, v[1], e.a.y), fmaf(scale, v[2], e.a.z), fmaf(scale, v[3], e.a.w)};
         store4p(p.out, p.out_plane, p.out_np, (int64_t)tok * p.ldc + n, o);
     } else if constexpr (EPI == EPI_HEADS_T) {
-        int b = m / p.T, t = m - b * p.T;
+        int b = fdiv(m, p.rT), t = m - b * p.T;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int nn = n + i;
-            int h = nn / p.hd, d = nn - h * p.hd;
+            int h = fdiv(nn, p.rhd), d = nn - h * p.hd;
             store1p(p.out, p.out_plane, p.out_np, ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t, v[i]);
         }
     } else if constexpr (EPI == EPI_QKV_ROPE) {
-        int sec = n / p.D;               // uniform over the 4 columns (D % 4 == 0)
+        int sec = fdiv(n, p.rD);         // uniform over the 4 columns (D % 4 == 0)
         int nn = n - sec * p.D;
-        int b = m / p.T, t = m - b * p.T;
+        int b = fdiv(m, p.rT), t = m - b * p.T;
         if (sec < 2) {
             const float c0 = e.a.x, c1 = e.a.y, s0 = e.a.z, s1 = e.a.w;
             float o[4] = {fmaf(v[0], c0, -(v[1] * s0)), fmaf(v[0], s0, v[1] * c0), fmaf(v[2], c1, -(v[3] * s1)), fmaf(v[2], s1, v[3] * c1)};
@@ -143,7 +148,7 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int c = nn + i;
-                int h = c / p.hd, d = c - h * p.hd;
+                int h = fdiv(c, p.rhd), d = c - h * p.hd;
                 store1p(p.vt, p.vt_plane, p.qkv_np, ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t, v[i]);
             }
         }
@@ -180,6 +185,108 @@ __device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&
                 float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
                 epi_store<EPI>(p, g, slot, tok, scale, n, v, pre[j][q]);
             }
+    }
+}
+
+// Block-wide epilogue staged through LDS (which is free once the k-loop is over).  The MFMA accumulator layout gives a lane
+// one output ROW and 4 consecutive columns, so direct stores put 8-16 B pieces of 32 different rows in every instruction.
+// Here a slab of 64 rows x BN columns goes to LDS as fp32 and is read back row-major: a lane still owns 4 consecutive
+// columns of one row (the epi_load / epi_store contract) but a wave now covers whole 128-B lines - residual / bias loads and
+// all stores are full-line transactions.  The V third of the QKV projection is staged TRANSPOSED instead and written as
+// 4 consecutive tokens of one (head, d) row: the per-head V^T image the attention kernel reads, in 8-B pieces of 128-B runs.
+// Needs 64 * (BN + 4) * 4 bytes of LDS (BN * 68 * 4 for the transposed variant).
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 (&acc)[TM][TN], float* stg, int row0, int rows_end,
+                                                int n0, int tid, int wr, int wc, int frow, int fk) {
+    constexpr int BNB = 64 * TN;
+    constexpr int PITCH = BNB + 4;               // floats; +4 keeps the 16-B column writes of 8 consecutive rows on distinct banks
+    constexpr int QPR = BNB / 4;                 // quads per row
+    constexpr int QPT = 64 * QPR / NTHREADS;     // quads per thread per slab
+    bool vsec = false;
+    if constexpr (EPI == EPI_QKV_ROPE) vsec = n0 >= 2 * p.D && (p.D % BNB) == 0 && (p.T & 3) == 0 && (p.Tpad & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): own LDS reads done (loop fragments / previous slab)
+        __builtin_amdgcn_s_barrier();
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            if (vsec) {
+                constexpr int PT = 64 + 4;       // transposed image [col][row]
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = wc * 32 * TN + j * 32 + (r >> 2) * 8 + fk * 4 + (r & 3);
+                        stg[col * PT + wr * 32 + frow] = acc[i][j][r];
+                    }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                constexpr int IPT = BNB * 16 / NTHREADS;
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) {
+                    const int idx = tid + k * NTHREADS;
+                    const int rq = idx & 15, c = idx >> 4;
+                    const int lr = rq * 4;
+                    const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
+                    const int n = n0 + c;
+                    if (slot >= rows_end || n >= p.N) continue;
+                    const float4 vv = *reinterpret_cast<const float4*>(stg + c * PT + lr);
+                    float v[4] = {vv.x, vv.y, vv.z, vv.w};
+                    const int nn = n - 2 * p.D;
+                    const int h = fdiv(nn, p.rhd), d = nn - h * p.hd;
+                    const int b = fdiv(slot, p.rT), t = slot - b * p.T;
+                    const int64_t base = ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad;
+                    if (slot + 3 < rows_end && t + 3 < p.T) {
+                        store4p(p.vt, p.vt_plane, p.qkv_np, base + t, v);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int m = slot + e;
+                            if (m >= rows_end) break;
+                            const int bb = fdiv(m, p.rT), tt = m - bb * p.T;
+                            store1p(p.vt, p.vt_plane, p.qkv_np, ((int64_t)(bb * p.H + h) * p.hd + d) * p.Tpad + tt, v[e]);
+                        }
+                    }
+                }
+                continue;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = wc * 32 * TN + j * 32 + q * 8 + fk * 4;
+                *reinterpret_cast<float4*>(stg + (wr * 32 + frow) * PITCH + col) =
+                    make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        EpiPre pre[QPT];
+        int slot_[QPT], tok_[QPT]; float scale_[QPT];
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int idx = tid + k * NTHREADS;
+            const int lr = idx / QPR, cq = idx - lr * QPR;
+            const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
+            const int n = n0 + cq * 4;
+            slot_[k] = (slot < rows_end && n < p.N) ? slot : -1;
+            tok_[k] = slot; scale_[k] = 1.f;
+            if (slot_[k] >= 0) {
+                if constexpr (EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES) {
+                    tok_[k] = p.rows_out[slot];
+                    scale_[k] = p.row_scale[tok_[k]];
+                }
+                epi_load<EPI>(p, g, slot, tok_[k], n, pre[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            if (slot_[k] < 0) continue;
+            const int idx = tid + k * NTHREADS;
+            const int lr = idx / QPR, cq = idx - lr * QPR;
+            const float4 vv = *reinterpret_cast<const float4*>(stg + lr * PITCH + cq * 4);
+            float v[4] = {vv.x, vv.y, vv.z, vv.w};
+            epi_store<EPI>(p, g, slot_[k], tok_[k], scale_[k], n0 + cq * 4, v, pre[k]);
+        }
     }
 }
 
@@ -317,6 +424,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     // s_waitcnt simm16 (gfx9): vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]; only vmcnt is counted here
     __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));
 }
+
+// which epilogues of the 128x128 kernel go through LDS (staged_epilogue) instead of storing from the MFMA layout
+#ifndef VB_STAGED_MASK
+#define VB_STAGED_MASK 0x91       /* measured per epilogue: PLANES, SWIGLU, GELU_PLANES gain; QKV_ROPE and the fp32 ones do not */
+#endif
+#define STAGED_EPI(E) (((VB_STAGED_MASK) >> (E)) & 1)
 
 // ABL (tuning only): 1 = no tile DMA in the loop, 2 = no MFMA, 3 = no LDS fragment reads
 template <int EPI, int BKT, int NST, int ABL = 0>
@@ -459,7 +572,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
             for (int j = 0; j < 2; ++j) sink += acc[i][j][0] + acc[i][j][9];
         if (sink == 12345.678f) p.out32[0] = sink;
     } else {
-        wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
+        if constexpr (STAGED_EPI(EPI)) staged_epilogue<EPI, 2, 2>(p, g, acc, reinterpret_cast<float*>(lds), row0, rows_end, n0, tid, wr, wc, frow, fk);
+        else wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
     }
     if constexpr (EPI == EPI_F32) {
         if (p.trace && tid == 0) {
@@ -653,53 +767,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
     }
 
     if constexpr (EPI == EPI_F32) { if (p.trace) t_loop = __builtin_amdgcn_s_memtime(); }
-    // ---- epilogue through LDS, one 64-row slab (32 rows of each wave row) at a time
-    constexpr int PITCH = BNB + 4;               // floats; +4 keeps the 16-B column writes of 8 consecutive rows on distinct banks
-    constexpr int QPR = BNB / 4;                 // quads per row
-    constexpr int QPT = 64 * QPR / NTHREADS;     // quads per thread per slab
-    float* stg = reinterpret_cast<float*>(ldsb);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): own LDS reads done (loop fragments / previous slab)
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = wc * 32 * TN + j * 32 + q * 8 + fk * 4;
-                *reinterpret_cast<float4*>(stg + (wr * 32 + frow) * PITCH + col) =
-                    make_float4(acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_s_barrier();
-        EpiPre pre[QPT];
-        int slot_[QPT], tok_[QPT]; float scale_[QPT];
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            const int idx = tid + k * NTHREADS;
-            const int lr = idx / QPR, cq = idx - lr * QPR;
-            const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
-            const int n = n0 + cq * 4;
-            slot_[k] = (slot < rows_end && n < p.N) ? slot : -1;
-            tok_[k] = slot; scale_[k] = 1.f;
-            if (slot_[k] >= 0) {
-                if constexpr (EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES) {
-                    tok_[k] = p.rows_out[slot];
-                    scale_[k] = p.row_scale[tok_[k]];
-                }
-                epi_load<EPI>(p, g, slot, tok_[k], n, pre[k]);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            if (slot_[k] < 0) continue;
-            const int idx = tid + k * NTHREADS;
-            const int lr = idx / QPR, cq = idx - lr * QPR;
-            const float4 vv = *reinterpret_cast<const float4*>(stg + lr * PITCH + cq * 4);
-            float v[4] = {vv.x, vv.y, vv.z, vv.w};
-            epi_store<EPI>(p, g, slot_[k], tok_[k], scale_[k], n0 + cq * 4, v, pre[k]);
-        }
-    }
+    staged_epilogue<EPI, TM, TN>(p, g, acc, reinterpret_cast<float*>(ldsb), row0, rows_end, n0, tid, wr, wc, frow, fk);
     if constexpr (EPI == EPI_F32) {
         if (p.trace && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);
@@ -775,6 +843,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
     d.qkv_np = a.q.np; d.rope_cos = a.rope_cos; d.rope_sin = a.rope_sin; d.H = a.H; d.hd = a.hd > 0 ? a.hd : 1;
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
+    d.rT = 1.0f / (float)d.T; d.rhd = 1.0f / (float)d.hd; d.rD = 1.0f / (float)d.D;
+    if (a.M >= (1 << 21) || (int64_t)a.N * (a.ngroups > 0 ? a.ngroups : 1) >= (1 << 21)) VB_FAIL(VB_E_INVALID, "gemm: index ranges exceed fdiv()");
     d.trace = g_gemm_trace;
     ProfScope prof(0, 2.0 * a.M * a.N * a.K * ((a.group_off || a.ngroups <= 1) ? 1 : a.ngroups), st);
     // tile configuration: 0 = 128x128 (two workgroups per CU), else (TM, TN) of the big-tile kernel (one per CU).  The
@@ -793,7 +863,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             const int64_t rt = a.group_off ? (cdiv(a.M, 192) + a.ngroups) : cdiv(a.M, 192);
             const int64_t t33 = rt * cdiv(a.N, 192) * gz;
             const int64_t t22 = (a.group_off ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
-            if (t33 <= 256 + 16 && t22 > 320) cfg = 33;
+            if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
         }
     }
     const int bm = cfg ? 64 * (cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10) : BN;
