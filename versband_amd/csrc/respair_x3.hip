@@ -110,12 +110,19 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
         }
     };
 
-    f32x16 acc[CH];
+    // two accumulator sets (hi*hi terms / cross terms): consecutive MFMAs never wait for each other's result
+    f32x16 acc[CH], acx[CH];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; acx[i][r] = 0.f; }
+    };
+    auto fold_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += acx[i][r];
     };
     // all taps of one ci chunk: B fragments from `src` rows (32*wave + l31 + j*step), A fragments from the weight tile
     auto taps = [&](const bf16_t* wsrc, int c0, const bf16_t* s0, const bf16_t* s1, int step) {
@@ -134,8 +141,8 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&wl[buf][0][o]);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(&wl[buf][1][o]);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                    acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acx[i], 0, 0, 0);
+                    acx[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acx[i], 0, 0, 0);
                 }
             }
             if (j + 1 < p.k) wstore(buf ^ 1);
@@ -155,6 +162,7 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
         if (ch + 1 < CH) xload((ch + 1) * 32);
         taps(p.w1, ch * 32, &xT[0][0], &xT[1][0], p.dil);
     }
+    fold_acc();
     {   // + b1, LeakyReLU, zero outside [0,T), split, to hT[chunk][plane][t][c]
         const int m = m0 + 32 * wave + l31;
         const bool inr = m >= 0 && m < p.T;
@@ -185,6 +193,7 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
         __syncthreads();       // (ch == 0: also publishes hT)
         taps(p.w2, ch * 32, &hT[ch][0][0], &hT[ch][1][0], 1);
     }
+    fold_acc();
     // ---- epilogue: lane owns output sample n (32 consecutive samples per co row across the half-wave)
     {
         const int nl = 32 * wave + l31;
@@ -213,6 +222,7 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
     }
 }
 
+
 int launch_respair(const RespairArgs& a, hipStream_t st) {
     if (a.C != 32 && a.C != 64) VB_FAIL(VB_E_INVALID, "respair: C=%d (32 or 64)", a.C);
     if (a.k < 1 || (a.k & 1) == 0 || (a.k - 1) * a.dil > RP_HALO || a.k > 33) VB_FAIL(VB_E_INVALID, "respair: k=%d dil=%d", a.k, a.dil);
@@ -225,6 +235,8 @@ int launch_respair(const RespairArgs& a, hipStream_t st) {
     dim3 grid(cdiv(a.T, TT), 1, a.B);
     // two convolutions' worth of flops (the recomputed halo of conv1 is not counted)
     ProfScope prof(2, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T, st);
+    // (a persistent variant with both convolutions' weights resident in LDS and the next window prefetched was measured slower,
+    //  460 / 900 / 1100 us against 440 / 620 / 830 us for k = 3 / 7 / 11: one workgroup per CU cannot hide its own phase latencies)
     if (a.C == 32) hipLaunchKernelGGL(respair_x3_kernel<1>, grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL(respair_x3_kernel<2>, grid, dim3(256), 0, st, d);
     VB_CHECK_LAUNCH();
