@@ -484,7 +484,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
         // B = 8 makes 288) runs as two rounds at 56 % - the 128co x 128t tile (71 KB, two per CU) halves the granule
         const int64_t blocks = (int64_t)cdiv(n_count, 256) * cdiv(a.Co, 128) * a.B * d.phases;
         const double eff = (double)blocks / (double)(cdiv(blocks, 256) * 256);
-        if (a.Co > 64 && eff < 0.7 && cfgv != 2) launch_cfg_x3<2, 2, 2, 1>(d, n_count, a.B, st);
+        if (a.Co > 64 && (eff < 0.7 || cfgv == 3) && cfgv != 2) launch_cfg_x3<2, 2, 2, 1>(d, n_count, a.B, st);
         else if (a.Co > 64) launch_cfg_x3<2, 2, 2, 2>(d, n_count, a.B, st);
         else if (a.Co > 32 && cfgv == 1) launch_cfg_x3<2, 2, 1, 4>(d, n_count, a.B, st);
         else if (a.Co > 32) launch_cfg_x3<2, 2, 1, 2>(d, n_count, a.B, st);

@@ -30,8 +30,13 @@ struct PairDev {
 template <int CH>      // C = 32*CH channels
 __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
     constexpr int C = 32 * CH;
-    __shared__ __attribute__((aligned(16))) bf16_t xT[2][RP_XW * RP_P];            // one ci chunk of the activated window
-    __shared__ __attribute__((aligned(16))) bf16_t hT[CH][2][RP_T * RP_P];         // activated intermediate, all chunks
+    // xT (one ci chunk of the activated window, conv1 only) and hT (activated intermediate, all chunks, conv2 only) share
+    // storage: hT is written after the barrier that ends conv1's last tap.  41 KB + weights instead of 72 KB: 3 workgroups
+    // per CU at 32 channels, 2 at 64 - these kernels are a chain of short phases and live off co-resident workgroups.
+    constexpr int XT_EL = 2 * RP_XW * RP_P, HT_EL = CH * 2 * RP_T * RP_P;
+    __shared__ __attribute__((aligned(16))) bf16_t xh[XT_EL > HT_EL ? XT_EL : HT_EL];
+    bf16_t (*xT)[RP_XW * RP_P] = reinterpret_cast<bf16_t (*)[RP_XW * RP_P]>(xh);
+    bf16_t (*hT)[2][RP_T * RP_P] = reinterpret_cast<bf16_t (*)[2][RP_T * RP_P]>(xh);
     __shared__ __attribute__((aligned(16))) bf16_t wl[2][2][C * RP_P];             // [buf][plane] one (tap, ci chunk) of weights
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -380,7 +380,7 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
     return ConvNet(ctx, L.NET_VAE, nb, zc, co, tm)
 
 
-def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split", fuse_pairs: Sequence[int] = (32,)) -> ConvNet:
+def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split", fuse_pairs: Sequence[int] = (32, 64)) -> ConvNet:
     """HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) as an op list; fully
     driven by the vocoder's config.yaml keys."""
     nb = NetBuilder(ctx.device, precision)
