@@ -53,7 +53,7 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-CLASS_KERNELS = {0: ("gemm_bf16",), 1: ("attn_kernel",), 2: ("conv1d_",)}
+CLASS_KERNELS = {0: ("gemm_bf16",), 1: ("attn_kernel",), 2: ("conv1d_", "respair_")}
 
 
 def pmc_traffic(cls):
