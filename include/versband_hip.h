@@ -171,14 +171,20 @@ typedef struct {
     float in_slope, out_slope, alpha, beta, acc_scale;
     const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
     const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution */
+    int in_stride, in_phase;                 /* VB_OP_CONV: the convolution reads x[i*in_stride + in_phase] (0/1 = plain) */
 } vb_net_op;
 
-enum { VB_NET_VAE = 0, VB_NET_VOCODER = 1 };
+enum { VB_NET_VAE = 0, VB_NET_VOCODER = 1, VB_NET_VAE_ENCODER = 2 };
+/* buffer lengths are T * tmul of the base length T passed at run time; in_tmul / out_tmul give the I/O tensors' lengths
+ * (decoder: 1 / 2; vocoder: 1 / hop; encoder: 2 / 1 with T = the latent length) */
 int vb_net_load(vb_ctx* ctx, int which, const vb_net_op* ops, int n_ops, const vb_buf_desc* bufs, int n_bufs, int in_channels,
-                int out_channels, int out_tmul);
+                int out_channels, int in_tmul, int out_tmul);
 size_t vb_net_workspace_bytes(vb_ctx* ctx, int which, int B, int T);
 /* decode_first_stage (ldm/models/diffusion/ddpm_audio.py:379-392): z [B][C][T] -> mel [B][80][2T] */
 int vb_vae_decode(vb_ctx* ctx, const float* z, int B, int T, float* mel, void* ws, void* stream);
+/* AutoencoderKL.encode (ldm/models/autoencoder1d.py:49-53, Encoder1D :315-409): mel [B][80][2T] -> moments [B][2*embed][T]
+ * (mean = first half of the channels, logvar = second half; DiagonalGaussianDistribution is applied by the caller) */
+int vb_vae_encode(vb_ctx* ctx, const float* mel, int B, int T, float* moments, void* ws, void* stream);
 /* HifiGAN.spec2wav (vocoder/hifigan/hifigan.py:20-30): mel [B][80][T] -> wav [B][T*hop] */
 int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream);
 

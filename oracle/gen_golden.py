@@ -39,6 +39,7 @@ GOLD = os.path.join(REPO, "tests", "golden")
 
 def _mod(name, **attrs):
     m = types.ModuleType(name)
+    m.__vb_stub__ = True
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m
@@ -309,6 +310,28 @@ def gen_vae(B=2, T=16):
     print("vae", mel.shape, float(mel.abs().max()))
 
 
+def gen_vae_encode(B=2, T_mel=32):
+    from ldm.models.autoencoder1d import AutoencoderKL
+    vcfg = synth.VAEConfig()
+    dd = dict(double_z=True, in_channels=80, out_ch=80, z_channels=20, kernel_size=5, ch=384, ch_mult=[1, 2, 4],
+              num_res_blocks=2, attn_layers=[3], down_layers=[0], dropout=0.0)
+    ae = AutoencoderKL(embed_dim=20, ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}).eval()
+    sd = synth.make_state_dict(synth.vae_encoder_shapes(vcfg), SEED + 3)
+    ref = {k: v for k, v in ae.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+    assert set(ref) == set(sd), set(ref) ^ set(sd)
+    for k in ref:
+        assert tuple(ref[k].shape) == tuple(sd[k].shape), (k, ref[k].shape, sd[k].shape)
+    ae.load_state_dict(sd, strict=False)
+    x = torch.from_numpy(prng.normal(prng.key_seed(SEED, "vae_enc_x"), B * 80 * T_mel).reshape(B, 80, T_mel))
+    eps = torch.from_numpy(prng.normal(prng.key_seed(SEED, "vae_enc_eps"), B * 20 * (T_mel // 2)).reshape(B, 20, T_mel // 2))
+    with torch.no_grad():
+        post = ae.encode(x)
+        z = post.mean + post.std * eps            # DiagonalGaussianDistribution.sample with the noise injected
+    np.savez_compressed(os.path.join(GOLD, "vae_encode.npz"), x=x.numpy(), moments=post.parameters.numpy(), eps=eps.numpy(),
+                        z=z.numpy(), mode=post.mode().numpy())
+    print("vae_encode", post.parameters.shape, float(post.parameters.abs().max()))
+
+
 def gen_hifigan(T=8):
     hg = load_by_path("ref_hifigan_modules", os.path.join(REF, "vocoder", "hifigan", "modules", "hifigan.py"))
     for tag, cfg in (("v1", synth.HifiGanConfig()),
@@ -332,15 +355,27 @@ def gen_hifigan(T=8):
         print("hifigan", tag, wav.shape, float(wav.abs().max()))
 
 
+def use_reference_paths():
+    """Make `import ldm...` / `vocoder...` / `utils...` resolve to the REFERENCE: its packages have no __init__.py (namespace
+    packages), so the build's same-named shim packages would win wherever they sit on sys.path.  versband_amd is already
+    imported; the repo root (and the cwd entry) leave sys.path and any cached shim modules are dropped."""
+    here = {os.path.abspath(p) for p in (REPO, os.getcwd())}
+    sys.path[:] = [REF] + [p for p in sys.path if p and os.path.abspath(p) not in here and p != REF]
+    for m in [m for m in sys.modules if m.split(".")[0] in ("ldm", "vocoder", "utils")]:
+        if not getattr(sys.modules[m], "__vb_stub__", False):
+            del sys.modules[m]
+
+
 def main():
     assert os.path.isdir(REF), "the reference is only available in the build container"
     os.makedirs(GOLD, exist_ok=True)
     install_stubs()
-    sys.path.insert(0, REF)
+    use_reference_paths()
     torch.set_grad_enabled(False)
     gen_dit(4, "e4")
     gen_dit(8, "e8", B=1, T=16, L=8)
     gen_vae()
+    gen_vae_encode()
     gen_hifigan()
     gen_sampler()
 

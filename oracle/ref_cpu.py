@@ -383,6 +383,40 @@ def vae_decode(sd: Dict[str, Tensor], z: Tensor, scale_factor: float = 1.0, pref
     return F.conv1d(h, w, g["decoder.conv_out.bias"], padding=w.shape[2] // 2)
 
 
+def vae_encode(sd: Dict[str, Tensor], x: Tensor, prefix: str = "") -> Tensor:
+    """AutoencoderKL.encode up to the posterior parameters (autoencoder1d.py:49-53): Encoder1D.forward (:383-409) then
+    quant_conv (:30).  x [B,80,T_mel] -> moments [B, 2*embed, T_mel/2^downs]; mean = first half of the channels."""
+    g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else sd
+    w = g["encoder.conv_in.weight"]
+    h = F.conv1d(x, w, g["encoder.conv_in.bias"], padding=w.shape[2] // 2)
+    levels = sorted({int(k.split(".")[2]) for k in g if k.startswith("encoder.down.")})
+    for lvl in levels:
+        nb = len({int(k.split(".")[4]) for k in g if k.startswith(f"encoder.down.{lvl}.block.")})
+        for b in range(nb):
+            h = _resblock(g, f"encoder.down.{lvl}.block.{b}.", h)
+            if f"encoder.down.{lvl}.attn.{b}.norm.weight" in g:
+                h = _attnblock(g, f"encoder.down.{lvl}.attn.{b}.", h)
+        if f"encoder.down.{lvl}.downsample.conv.weight" in g:                 # Downsample1D :294-313
+            h = F.pad(h, (0, 1), mode="constant", value=0)
+            h = F.conv1d(h, g[f"encoder.down.{lvl}.downsample.conv.weight"], g[f"encoder.down.{lvl}.downsample.conv.bias"], stride=2)
+    h = _resblock(g, "encoder.mid.block_1.", h)
+    h = _attnblock(g, "encoder.mid.attn_1.", h)
+    h = _resblock(g, "encoder.mid.block_2.", h)
+    h = _gn_swish(h, g["encoder.norm_out.weight"], g["encoder.norm_out.bias"])
+    w = g["encoder.conv_out.weight"]
+    h = F.conv1d(h, w, g["encoder.conv_out.bias"], padding=w.shape[2] // 2)
+    return F.conv1d(h, g["quant_conv.weight"], g["quant_conv.bias"])
+
+
+def gaussian_posterior(moments: Tensor, noise: Tensor = None, scale_factor: float = 1.0) -> Tensor:
+    """DiagonalGaussianDistribution (ldm/modules/distributions/distributions.py:4-27) + get_first_stage_encoding
+    (ddpm_audio.py:163-170): logvar clamped to [-30, 20]; sample = mean + exp(0.5 logvar) * noise (mode when noise is None)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
+    return scale_factor * z
+
+
 # ---------------------------------------------------------------------------
 # HiFi-GAN generator
 # ---------------------------------------------------------------------------

@@ -134,6 +134,32 @@ def test_vae_decode_vs_golden_and_oracle(ctx, prec, tol):
     assert rel_l2(mel, ref) < tol, describe("vae_decode T=151 vs oracle", mel, ref)
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("split", 2e-4)])
+def test_vae_encode_vs_golden_and_oracle(ctx, prec, tol):
+    """Encoder1D (k5 ResnetBlocks, stride-2 Downsample1D as two polyphase convolutions, mid attention) +
+    quant_conv through vb_vae_encode; posterior sample/mode through the reference-named API."""
+    from versband_amd.engine import build_vae_encoder
+    from versband_amd.model import DiagonalGaussianDistribution
+    sde = synth.make_state_dict(synth.vae_encoder_shapes(synth.VAEConfig()), SEED + 3)
+    enc = build_vae_encoder(ctx, sde, precision=prec)
+    g = np.load(os.path.join(GOLD, "vae_encode.npz"))
+    mom = enc.run(torch.from_numpy(g["x"]))
+    torch.cuda.synchronize()
+    assert rel_l2(mom, g["moments"]) < tol, describe("vae_encode vs reference", mom, g["moments"])
+    post = DiagonalGaussianDistribution(mom)
+    assert rel_l2(post.sample(torch.from_numpy(g["eps"])), g["z"]) < tol
+    assert rel_l2(post.mode(), g["mode"]) < tol
+    # ragged mel length (T_mel = 302 -> 151 latent frames, not a tile multiple) vs the oracle
+    x = torch.from_numpy(synth.prng.normal(78, 1 * 80 * 302).reshape(1, 80, 302))
+    ref = ref_cpu.vae_encode(sde, x)
+    mom = enc.run(x)
+    torch.cuda.synchronize()
+    assert mom.shape == ref.shape
+    assert rel_l2(mom, ref) < tol, describe("vae_encode T_mel=302 vs oracle", mom, ref)
+    with pytest.raises(ValueError):
+        enc.run(torch.zeros(1, 80, 301))          # odd mel length cannot be halved (the reference pads to a multiple of 8 upstream)
+
+
 @pytest.mark.parametrize("tag", ["v1", "rb2"])
 @pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("split", 2e-4)])
 def test_hifigan_vs_golden_and_oracle(ctx, tag, prec, tol):

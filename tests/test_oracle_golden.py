@@ -58,6 +58,17 @@ def test_vae_decode_matches_reference(golden_dir):
     assert _rel(mel, g["mel"]) < 2e-6
 
 
+def test_vae_encode_matches_reference(golden_dir):
+    """Encoder1D + quant_conv + DiagonalGaussianDistribution against the reference's AutoencoderKL.encode."""
+    g = _load(golden_dir, "vae_encode.npz")
+    sd = synth.make_state_dict(synth.vae_encoder_shapes(synth.VAEConfig()), SEED + 3)
+    mom = ref_cpu.vae_encode(sd, torch.from_numpy(g["x"]))
+    assert mom.shape == g["moments"].shape
+    assert _rel(mom, g["moments"]) < 2e-6
+    assert _rel(ref_cpu.gaussian_posterior(mom, torch.from_numpy(g["eps"])), g["z"]) < 2e-6
+    assert _rel(ref_cpu.gaussian_posterior(mom), g["mode"]) < 2e-6
+
+
 @pytest.mark.parametrize("tag", ["v1", "rb2"])
 def test_hifigan_matches_reference(golden_dir, tag):
     g = _load(golden_dir, f"hifigan_{tag}.npz")

@@ -53,13 +53,13 @@ class NetOp(C.Structure):
                 + [(n, c_int) for n in ("Ci", "Co", "ksize", "dil", "pad", "upsample2", "in_act", "out_act", "out_transposed",
                                         "tr_stride", "tr_pad", "tr_k", "gn_groups")]
                 + [(n, c_float) for n in ("in_slope", "out_slope", "alpha", "beta", "acc_scale")]
-                + [("w_x3", c_void_p), ("ci_pad", c_int), ("w2_x3", c_void_p), ("bias2", c_void_p)])
+                + [("w_x3", c_void_p), ("ci_pad", c_int), ("w2_x3", c_void_p), ("bias2", c_void_p), ("in_stride", c_int), ("in_phase", c_int)])
 
 
 OP_CONV, OP_GN_STATS, OP_SOFTMAX_T, OP_SPLIT_PLANES, OP_RESPAIR, OP_GN_APPLY = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_LRELU, ACT_GN_SWISH, ACT_TANH, ACT_GN = 0, 1, 2, 3, 4
 BUF_INPUT, BUF_OUTPUT = -2, -3
-NET_VAE, NET_VOCODER = 0, 1
+NET_VAE, NET_VOCODER, NET_VAE_ENCODER = 0, 1, 2
 
 # name -> (restype, argtypes); the list doubles as the export check of tests/test_abi.py
 P = c_void_p
@@ -77,9 +77,10 @@ PROTOTYPES = {
     "vb_dit_forward": (c_int, [P, P, P, P, C.POINTER(Noise), c_int, c_int, c_int, c_int, P, P, P, P]),
     "vb_euler_cfg_step": (c_int, [P, P, c_int, c_i64, c_float, c_float, c_int, P]),
     "vb_sample_cfg": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, C.POINTER(Noise), P, P, P]),
-    "vb_net_load": (c_int, [P, c_int, C.POINTER(NetOp), c_int, C.POINTER(BufDesc), c_int, c_int, c_int, c_int]),
+    "vb_net_load": (c_int, [P, c_int, C.POINTER(NetOp), c_int, C.POINTER(BufDesc), c_int, c_int, c_int, c_int, c_int]),
     "vb_net_workspace_bytes": (c_size_t, [P, c_int, c_int, c_int]),
     "vb_vae_decode": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_vae_encode": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_hifigan_forward": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_rmsnorm_modulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, P]),
     "vb_router_top1": (c_int, [P, P, c_int, c_int, P, P]),

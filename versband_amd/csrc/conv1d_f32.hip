@@ -26,6 +26,7 @@ struct ConvDev {
     const float* x; int64_t x_bstride; int Ci, T_in, x_bmod;
     const float* w; int64_t w_bstride; const float* bias;
     int Co, ntaps, dil, pad, upsample2;
+    int in_stride, in_phase;        // the convolution sees xd[i] = x[i * in_stride + in_phase] (strided down-convs as polyphase sums)
     int in_act; float in_slope;
     const float* gn_mean; const float* gn_rstd; const float* gn_gamma; const float* gn_beta; int gn_groups;
     float* out; int64_t out_bstride; int T_out;
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256) conv1d_f32_kernel(const ConvDev p) {
 
     const int halo = (p.ntaps - 1) * p.dil;
     const int xw_used = T_TILE + halo;
-    const int T_eff = p.upsample2 ? 2 * p.T_in : p.T_in;
+    const int T_eff = p.upsample2 ? 2 * p.T_in : (p.T_in - p.in_phase + p.in_stride - 1) / p.in_stride;
     const int xb = p.x_bmod > 0 ? (b % p.x_bmod) : b;
     const float* xbase = p.x + (int64_t)xb * p.x_bstride;
     const float* wbase = p.w + (int64_t)b * p.w_bstride + (int64_t)ph * p.ntaps * p.Ci * p.Co;
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) conv1d_f32_kernel(const ConvDev p) {
                 const int idx = n0 + in_off + wpos;
                 float v = 0.f;
                 if (cok && idx >= 0 && idx < T_eff) {
-                    v = xrow[p.upsample2 ? (idx >> 1) : idx];
+                    v = xrow[p.upsample2 ? (idx >> 1) : idx * p.in_stride + p.in_phase];
                     if (p.in_act == ACT_LRELU) {
                         v = v > 0.f ? v : v * p.in_slope;
                     } else if (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN) {
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
 
     const int halo = (p.ntaps - 1) * p.dil;
     const int xw_used = T_TILE + halo;
-    const int T_eff = p.upsample2 ? 2 * p.T_in : p.T_in;
+    const int T_eff = p.upsample2 ? 2 * p.T_in : (p.T_in - p.in_phase + p.in_stride - 1) / p.in_stride;
     const int xb = p.x_bmod > 0 ? (b % p.x_bmod) : b;
     const float* xbase = p.x + (int64_t)xb * p.x_bstride;
     const bf16_t* wbase = p.wp + (int64_t)b * p.wp_bstride + (int64_t)ph * p.ntaps * p.Co * p.Ci_pad;
@@ -342,7 +343,7 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
                 for (int it = 0; it < NIT; ++it) {
                     const int idx = n0 + in_off + lane + 64 * it;
                     const bool ok = cok && (lane + 64 * it) < xw_used && idx >= 0 && idx < T_eff;
-                    raw[cpi][it][e] = ok ? xrow[p.upsample2 ? (idx >> 1) : idx] : 0.f;
+                    raw[cpi][it][e] = ok ? xrow[p.upsample2 ? (idx >> 1) : idx * p.in_stride + p.in_phase] : 0.f;
                 }
             }
         }
@@ -458,6 +459,8 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     d.x = a.x; d.x_bstride = a.x_bstride; d.Ci = a.Ci; d.T_in = a.T_in; d.x_bmod = a.x_bmod;
     d.w = a.w; d.w_bstride = a.w_bstride; d.bias = a.bias; d.Co = a.Co; d.dil = a.dil; d.pad = a.pad;
     d.upsample2 = a.upsample2; d.in_act = a.in_act; d.in_slope = a.in_slope;
+    d.in_stride = a.in_stride > 0 ? a.in_stride : 1; d.in_phase = a.in_phase;
+    if (d.in_stride > 1 && (a.upsample2 || a.tr_stride > 1)) VB_FAIL(VB_E_INVALID, "conv1d: in_stride with upsample/transpose");
     d.gn_mean = a.gn_mean; d.gn_rstd = a.gn_rstd; d.gn_gamma = a.gn_gamma; d.gn_beta = a.gn_beta; d.gn_groups = a.gn_groups;
     d.out = a.out; d.out_bstride = a.out_bstride; d.T_out = a.T_out; d.res = a.res; d.res_bstride = a.res_bstride;
     d.alpha = a.alpha; d.beta = a.beta; d.acc_scale = a.acc_scale; d.out_act = a.out_act; d.out_slope = a.out_slope;

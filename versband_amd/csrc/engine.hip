@@ -52,7 +52,7 @@ void prof_stop(int cls, hipStream_t st) {
 struct NetProgram {
     std::vector<vb_net_op> ops;
     std::vector<vb_buf_desc> bufs;
-    int in_ch = 0, out_ch = 0, out_tmul = 1;
+    int in_ch = 0, out_ch = 0, in_tmul = 1, out_tmul = 1;
     bool loaded = false;
 };
 struct vb_ctx {
@@ -60,7 +60,7 @@ struct vb_ctx {
     bool dit_loaded = false;
     vb_dit_config cfg;
     vb_dit_weights w;
-    NetProgram nets[2];
+    NetProgram nets[3];
 };
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -415,7 +415,7 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
         return reinterpret_cast<float*>(static_cast<char*>(ws) + offs[id]);
     };
     auto tlen = [&](int id) -> int {
-        if (id == VB_BUF_INPUT) return T;
+        if (id == VB_BUF_INPUT) return T * n.in_tmul;
         if (id == VB_BUF_OUTPUT) return T * n.out_tmul;
         return T * n.bufs[id].tmul;
     };
@@ -441,6 +441,7 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
             a.Ci = o.Ci > 0 ? o.Ci : tlen(o.x);            // dynamic channel counts: the VAE attention contracts over T
             if (o.w_buf != -1) { a.w = ptr(o.w_buf); a.w_bstride = bstride(o.w_buf); } else { a.w = o.w; }
             a.bias = o.bias; a.Co = o.Co > 0 ? o.Co : tlen(o.out); a.ksize = o.ksize; a.dil = o.dil; a.pad = o.pad; a.upsample2 = o.upsample2;
+            a.in_stride = o.in_stride > 1 ? o.in_stride : 1; a.in_phase = o.in_phase;
             a.in_act = o.in_act; a.in_slope = o.in_slope;
             if (o.stats >= 0) {
                 float* stp = ptr(o.stats);
@@ -610,8 +611,8 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
 }
 
 int vb_net_load(vb_ctx* ctx, int which, const vb_net_op* ops, int n_ops, const vb_buf_desc* bufs, int n_bufs, int in_channels,
-                int out_channels, int out_tmul) {
-    if (!ctx || which < 0 || which > 1 || !ops || n_ops < 1) VB_FAIL(VB_E_INVALID, "net_load: bad argument");
+                int out_channels, int in_tmul, int out_tmul) {
+    if (!ctx || which < 0 || which > 2 || !ops || n_ops < 1 || in_tmul < 1 || out_tmul < 1) VB_FAIL(VB_E_INVALID, "net_load: bad argument");
     NetProgram& n = ctx->nets[which];
     n.ops.assign(ops, ops + n_ops);
     n.bufs.assign(bufs, bufs + n_bufs);
@@ -621,16 +622,20 @@ int vb_net_load(vb_ctx* ctx, int which, const vb_net_op* ops, int n_ops, const v
         for (int id : ids)
             if (id >= n_bufs || (id < -3)) VB_FAIL(VB_E_INVALID, "net_load: op %d references buffer %d of %d", i, id, n_bufs);
     }
-    n.in_ch = in_channels; n.out_ch = out_channels; n.out_tmul = out_tmul; n.loaded = true;
+    n.in_ch = in_channels; n.out_ch = out_channels; n.in_tmul = in_tmul; n.out_tmul = out_tmul; n.loaded = true;
     return VB_OK;
 }
 size_t vb_net_workspace_bytes(vb_ctx* ctx, int which, int B, int T) {
-    if (!ctx || which < 0 || which > 1 || !ctx->nets[which].loaded) return 0;
+    if (!ctx || which < 0 || which > 2 || !ctx->nets[which].loaded) return 0;
     return net_ws_bytes(ctx->nets[which], B, T, nullptr);
 }
 int vb_vae_decode(vb_ctx* ctx, const float* z, int B, int T, float* mel, void* ws, void* stream) {
     if (!ctx) VB_FAIL(VB_E_INVALID, "vae_decode: null ctx");
     return net_run(ctx, VB_NET_VAE, z, B, T, mel, ws, (hipStream_t)stream);
+}
+int vb_vae_encode(vb_ctx* ctx, const float* mel, int B, int T, float* moments, void* ws, void* stream) {
+    if (!ctx) VB_FAIL(VB_E_INVALID, "vae_encode: null ctx");
+    return net_run(ctx, VB_NET_VAE_ENCODER, mel, B, T, moments, ws, (hipStream_t)stream);
 }
 int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream) {
     if (!ctx) VB_FAIL(VB_E_INVALID, "hifigan_forward: null ctx");

@@ -68,6 +68,7 @@ struct ConvArgs {
     const float* bias = nullptr;
     int Co = 0, ksize = 1, dil = 1, pad = 0;
     int upsample2 = 0;               // nearest x2 on the input (T_in is the un-upsampled length)
+    int in_stride = 1, in_phase = 0; // the convolution reads x[i * in_stride + in_phase] (Downsample1D as two polyphase convs)
     int in_act = ACT_NONE; float in_slope = 0.f;
     const float* gn_mean = nullptr; const float* gn_rstd = nullptr;   // [B][groups]
     const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int gn_groups = 32;

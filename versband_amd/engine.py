@@ -212,7 +212,7 @@ class NetBuilder:
     def conv(self, x: int, out: int, Ci: int, Co: int, w: Optional[Tensor] = None, bias: Optional[Tensor] = None, k: int = 1,
              dil: int = 1, pad: int = 0, res: int = -1, stats: int = -1, gamma=None, beta_gn=None, in_act=L.ACT_NONE,
              in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
-             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32, w_buf_planes=False):
+             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32, w_buf_planes=False, in_stride=1, in_phase=0):
         w_x3, ci_pad = None, (-1 if w_buf_planes else 0)
         tmp = -1
         if (self.precision == "split" and in_act in (L.ACT_GN_SWISH, L.ACT_GN) and stats >= 0 and x >= 0 and Co >= self.GN_PREPASS_MIN_CO
@@ -228,7 +228,7 @@ class NetBuilder:
                      gn_gamma=self._t(gamma), gn_beta=self._t(beta_gn), Ci=Ci, Co=Co, ksize=k, dil=dil, pad=pad,
                      upsample2=upsample2, in_act=in_act, out_act=out_act, out_transposed=out_transposed, tr_stride=tr_stride,
                      tr_pad=tr_pad, tr_k=tr_k, gn_groups=groups, in_slope=in_slope, out_slope=out_slope, alpha=alpha, beta=beta,
-                     acc_scale=acc_scale, w_x3=w_x3, ci_pad=ci_pad)
+                     acc_scale=acc_scale, w_x3=w_x3, ci_pad=ci_pad, in_stride=in_stride, in_phase=in_phase)
         self.ops.append(op)
         self.release(tmp)
 
@@ -243,13 +243,14 @@ class NetBuilder:
 
 
 class ConvNet:
-    def __init__(self, ctx: Context, which: int, nb: NetBuilder, in_ch: int, out_ch: int, out_tmul: int):
+    def __init__(self, ctx: Context, which: int, nb: NetBuilder, in_ch: int, out_ch: int, out_tmul: int, in_tmul: int = 1):
         ctx = Context(ctx.device)        # one program per (vb_ctx, slot): every net owns its handle
         self.ctx, self.which, self.nb = ctx, which, nb
-        self.in_ch, self.out_ch, self.out_tmul = in_ch, out_ch, out_tmul
+        self.in_ch, self.out_ch, self.out_tmul, self.in_tmul = in_ch, out_ch, out_tmul, in_tmul
         ops = (L.NetOp * len(nb.ops))(*nb.ops)
         bufs = (L.BufDesc * max(1, len(nb.bufs)))(*[L.BufDesc(*b) for b in nb.bufs])
-        L.check(ctx.lib.vb_net_load(ctx.handle, which, ops, len(nb.ops), bufs, len(nb.bufs), in_ch, out_ch, out_tmul), "vb_net_load")
+        L.check(ctx.lib.vb_net_load(ctx.handle, which, ops, len(nb.ops), bufs, len(nb.bufs), in_ch, out_ch, in_tmul, out_tmul),
+                "vb_net_load")
         self._ws = None
         self._ws_key = None
 
@@ -262,21 +263,21 @@ class ConvNet:
 
     def run(self, x: Tensor) -> Tensor:
         x = x.to(self.ctx.device, torch.float32).contiguous()
-        B, Cin, T = x.shape
+        B, Cin, Tin = x.shape
         assert Cin == self.in_ch, (Cin, self.in_ch)
+        if Tin % self.in_tmul:
+            raise ValueError(f"input length {Tin} is not a multiple of {self.in_tmul}")
+        T = Tin // self.in_tmul
         out = torch.empty(B, self.out_ch, T * self.out_tmul, dtype=torch.float32, device=self.ctx.device)
         ws = self._workspace(B, T)
-        fn = self.ctx.lib.vb_vae_decode if self.which == L.NET_VAE else self.ctx.lib.vb_hifigan_forward
+        fn = {L.NET_VAE: self.ctx.lib.vb_vae_decode, L.NET_VOCODER: self.ctx.lib.vb_hifigan_forward,
+              L.NET_VAE_ENCODER: self.ctx.lib.vb_vae_encode}[self.which]
         L.check(fn(self.ctx.handle, L.ptr(x), B, T, L.ptr(out), L.ptr(ws), L.stream_ptr()), "conv net run")
         return out
 
 
-def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float = 1.0, precision: str = "split") -> ConvNet:
-    """AutoencoderKL.decode (autoencoder1d.py:55-58) + Decoder1D.forward (:480-512) as an op list.
-    The structure (levels, shortcut convs, attention blocks, which level upsamples) is read off the
-    key names, exactly what load_state_dict would accept."""
-    nb = NetBuilder(ctx.device, precision)
-    g = sd
+def _vae_block_builders(nb: "NetBuilder", g: Dict[str, Tensor]):
+    """(cw, resblock, attnblock) emitting ResnetBlock1D (autoencoder1d.py:172-231) / AttnBlock1D (:233-274) ops into nb."""
 
     def cw(name):
         return pack.pack_conv(g[name + ".weight"]), g[name + ".bias"]
@@ -286,7 +287,8 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
         st1 = nb.gn_stats(x, cin)
         t1 = nb.buf(cout, tm)
         w, b = cw(p + "conv1")
-        nb.conv(x, t1, cin, cout, w, b, k=3, pad=1, stats=st1, gamma=g[p + "norm1.weight"], beta_gn=g[p + "norm1.bias"],
+        kk = g[p + "conv1.weight"].shape[2]      # 3 in the decoder, ddconfig.kernel_size in the encoder (autoencoder1d.py:346-351)
+        nb.conv(x, t1, cin, cout, w, b, k=kk, pad=kk // 2, stats=st1, gamma=g[p + "norm1.weight"], beta_gn=g[p + "norm1.bias"],
                 in_act=L.ACT_GN_SWISH)
         nb.release(st1)
         st2 = nb.gn_stats(t1, cout)
@@ -297,7 +299,8 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
             nb.conv(x, sc, cin, cout, w, b)
         out = nb.buf(cout, tm)
         w, b = cw(p + "conv2")
-        nb.conv(t1, out, cout, cout, w, b, k=3, pad=1, res=sc, stats=st2, gamma=g[p + "norm2.weight"], beta_gn=g[p + "norm2.bias"],
+        kk = g[p + "conv2.weight"].shape[2]
+        nb.conv(t1, out, cout, cout, w, b, k=kk, pad=kk // 2, res=sc, stats=st2, gamma=g[p + "norm2.weight"], beta_gn=g[p + "norm2.bias"],
                 in_act=L.ACT_GN_SWISH)
         nb.release(st2); nb.release(t1)
         if sc != x:
@@ -345,6 +348,17 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
             nb.release(t)
         return out
 
+    return cw, resblock, attnblock
+
+
+def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float = 1.0, precision: str = "split") -> ConvNet:
+    """AutoencoderKL.decode (autoencoder1d.py:55-58) + Decoder1D.forward (:480-512) as an op list.
+    The structure (levels, shortcut convs, attention blocks, which level upsamples) is read off the
+    key names, exactly what load_state_dict would accept."""
+    nb = NetBuilder(ctx.device, precision)
+    g = sd
+    cw, resblock, attnblock = _vae_block_builders(nb, g)
+
     zc = g["post_quant_conv.weight"].shape[1]
     h = nb.buf(g["post_quant_conv.weight"].shape[0], 1)
     w, b = cw("post_quant_conv")
@@ -378,6 +392,50 @@ def build_vae_decoder(ctx: Context, sd: Dict[str, Tensor], scale_factor: float =
     nb.conv(h, L.BUF_OUTPUT, c, co, w, b, k=kk, pad=kk // 2, stats=st, gamma=g["decoder.norm_out.weight"],
             beta_gn=g["decoder.norm_out.bias"], in_act=L.ACT_GN_SWISH)
     return ConvNet(ctx, L.NET_VAE, nb, zc, co, tm)
+
+
+def build_vae_encoder(ctx: Context, sd: Dict[str, Tensor], precision: str = "split") -> ConvNet:
+    """AutoencoderKL.encode up to the moments (autoencoder1d.py:49-53: Encoder1D.forward :383-409, then quant_conv :30):
+    mel [B,in_ch,T_mel] -> [B, 2*embed_dim, T_mel / 2^len(down_layers)].  Structure read off the key names.
+    Downsample1D (:294-313: pad right by one, Conv1d k3 stride 2) runs as two polyphase convolutions on the same kernels:
+    out[n] = w0 x[2n] + w2 x[2n+2]  (taps 0 and 2 over the even samples)  +  w1 x[2n+1]  (tap 1 over the odd samples)."""
+    nb = NetBuilder(ctx.device, precision)
+    g = sd
+    cw, resblock, attnblock = _vae_block_builders(nb, g)
+    levels = sorted({int(k.split(".")[2]) for k in g if k.startswith("encoder.down.")})
+    n_down = sum(1 for lvl in levels if f"encoder.down.{lvl}.downsample.conv.weight" in g)
+    tm = 2 ** n_down
+    w, b = cw("encoder.conv_in")
+    cin, c, kk = g["encoder.conv_in.weight"].shape[1], g["encoder.conv_in.weight"].shape[0], g["encoder.conv_in.weight"].shape[2]
+    h = nb.buf(c, tm)
+    nb.conv(L.BUF_INPUT, h, cin, c, w, b, k=kk, pad=kk // 2)
+    for lvl in levels:
+        nblk = len({int(k.split(".")[4]) for k in g if k.startswith(f"encoder.down.{lvl}.block.")})
+        for bi in range(nblk):
+            h, c = resblock(h, c, tm, f"encoder.down.{lvl}.block.{bi}.")
+            if f"encoder.down.{lvl}.attn.{bi}.norm.weight" in g:
+                h = attnblock(h, c, tm, f"encoder.down.{lvl}.attn.{bi}.")
+        if f"encoder.down.{lvl}.downsample.conv.weight" in g:
+            wd, bd = g[f"encoder.down.{lvl}.downsample.conv.weight"].float(), g[f"encoder.down.{lvl}.downsample.conv.bias"]
+            assert wd.shape[2] == 3 and tm % 2 == 0
+            h2 = nb.buf(c, tm // 2)
+            nb.conv(h, h2, c, c, pack.pack_conv(wd[:, :, 0::2].contiguous()), bd, k=2, pad=0, in_stride=2, in_phase=0)
+            nb.conv(h, h2, c, c, pack.pack_conv(wd[:, :, 1:2].contiguous()), None, k=1, pad=0, in_stride=2, in_phase=1, beta=1.0)
+            nb.release(h)
+            h, tm = h2, tm // 2
+    h, c = resblock(h, c, tm, "encoder.mid.block_1.")
+    h = attnblock(h, c, tm, "encoder.mid.attn_1.")
+    h, c = resblock(h, c, tm, "encoder.mid.block_2.")
+    st = nb.gn_stats(h, c)
+    w, b = cw("encoder.conv_out")
+    co, kk = g["encoder.conv_out.weight"].shape[0], g["encoder.conv_out.weight"].shape[2]
+    m = nb.buf(co, tm)
+    nb.conv(h, m, c, co, w, b, k=kk, pad=kk // 2, stats=st, gamma=g["encoder.norm_out.weight"], beta_gn=g["encoder.norm_out.bias"],
+            in_act=L.ACT_GN_SWISH)
+    w, b = cw("quant_conv")
+    nb.conv(m, L.BUF_OUTPUT, co, g["quant_conv.weight"].shape[0], w, b)
+    assert tm == 1
+    return ConvNet(ctx, L.NET_VAE_ENCODER, nb, cin, g["quant_conv.weight"].shape[0], 1, in_tmul=2 ** n_down)
 
 
 def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split", fuse_pairs: Sequence[int] = (32, 64)) -> ConvNet:

@@ -114,10 +114,43 @@ class AutoencoderKL:
 
     def load_state_dict(self, sd, strict=False):
         self.state = {k: v for k, v in sd.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+        self.enc_state = {k: v for k, v in sd.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
         self.net = None
+        self.enc_net = None
+
+    enc_state: Dict[str, Tensor] = {}
+    enc_net = None
+    _device = None
 
     def encode(self, x):
-        raise NotImplementedError("the VAE encoder is outside the accelerated inference path (SURVEY §8f N2)")
+        """:49-53  mel [B,80,T_mel] -> DiagonalGaussianDistribution over z [B,embed_dim,T_mel/2] (HIP encoder net)."""
+        from .engine import Context, build_vae_encoder
+        if self.enc_net is None:
+            if not self.enc_state:
+                raise RuntimeError("AutoencoderKL.encode: no encoder.* / quant_conv.* weights loaded")
+            self.enc_net = build_vae_encoder(Context(self._device or "cuda:0"), self.enc_state)
+        return DiagonalGaussianDistribution(self.enc_net.run(x))
+
+
+class DiagonalGaussianDistribution:
+    """ldm/modules/distributions/distributions.py:4-43 (inference members)."""
+
+    def __init__(self, parameters: Tensor, deterministic: bool = False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, noise: Optional[Tensor] = None):
+        eps = torch.randn(self.mean.shape, device=self.mean.device) if noise is None else noise.to(self.mean.device)
+        return self.mean + self.std * eps
+
+    def mode(self):
+        return self.mean
 
 
 class DiffusionWrapper:
@@ -263,6 +296,22 @@ class CFM:
         pc = self._precompute([cond], x_noisy.shape[-1])
         v = self.dit_engine().forward(x_noisy, t, pc, seed=int(torch.initial_seed()) & 0xFFFFFFFF)
         return v, torch.zeros((), device=v.device)
+
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        """ddpm_audio.py:411-412."""
+        self.first_stage_model._device = self._context().device
+        return self.first_stage_model.encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        """ddpm_audio.py:163-170."""
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample()
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return float(self.scale_factor) * z
 
     @torch.no_grad()
     def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):

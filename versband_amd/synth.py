@@ -212,6 +212,54 @@ def vae_decoder_shapes(cfg: VAEConfig):
     return s
 
 
+
+def vae_encoder_shapes(cfg: VAEConfig):
+    """encoder.* + quant_conv keys of AutoencoderKL (autoencoder1d.py:30,315-381).  Encoder ResnetBlocks take the
+    ddconfig kernel_size (:346-351), unlike the decoder's default 3."""
+    s: "OrderedDict[str, Tuple[Tuple[int, ...], tuple]]" = OrderedDict()
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"] = ((co, ci, k), ("fan",))
+        s[name + ".bias"] = ((co,), ("u", 0.02))
+
+    def norm(name, c):
+        s[name + ".weight"] = ((c,), ("norm",))
+        s[name + ".bias"] = ((c,), ("u", 0.05))
+
+    def res(name, ci, co):
+        norm(name + ".norm1", ci)
+        conv(name + ".conv1", co, ci, cfg.kernel_size)
+        norm(name + ".norm2", co)
+        conv(name + ".conv2", co, co, cfg.kernel_size)
+        if ci != co:
+            conv(name + ".nin_shortcut", co, ci, 1)
+
+    def attn(name, c):
+        norm(name + ".norm", c)
+        for nm in ("q", "k", "v", "proj_out"):
+            conv(name + "." + nm, c, c, 1)
+
+    conv("encoder.conv_in", cfg.ch, cfg.in_channels, cfg.kernel_size)
+    in_mult = (1,) + tuple(cfg.ch_mult)
+    block_in = cfg.ch
+    for lvl in range(len(cfg.ch_mult)):
+        block_in = cfg.ch * in_mult[lvl]
+        block_out = cfg.ch * cfg.ch_mult[lvl]
+        for b in range(cfg.num_res_blocks):
+            res(f"encoder.down.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+            if lvl in cfg.attn_layers:
+                attn(f"encoder.down.{lvl}.attn.{b}", block_in)
+        if lvl in cfg.down_layers:
+            conv(f"encoder.down.{lvl}.downsample.conv", block_in, block_in, 3)
+    res("encoder.mid.block_1", block_in, block_in)
+    attn("encoder.mid.attn_1", block_in)
+    res("encoder.mid.block_2", block_in, block_in)
+    norm("encoder.norm_out", block_in)
+    conv("encoder.conv_out", 2 * cfg.z_channels, block_in, cfg.kernel_size)
+    conv("quant_conv", 2 * cfg.embed_dim, 2 * cfg.z_channels, 1)
+    return s
+
 def hifigan_shapes(cfg: HifiGanConfig):
     s: "OrderedDict[str, Tuple[Tuple[int, ...], tuple]]" = OrderedDict()
 
