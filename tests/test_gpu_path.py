@@ -274,6 +274,24 @@ def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0])
 
 
+def test_fused_band_experts_match_two_gemm_path(engines, monkeypatch):
+    """bf16 production mode runs the band experts as ONE launch (w1/w3 -> SwiGLU -> w2, hidden kept in LDS); it walks K in
+    the same order as the two grouped GEMMs and shares their epilogue code, so the results must be bit-identical."""
+    eng = engines[(4, "bf16")]
+    B, T, Lc = 2, 752, 80
+    inp = clip_batch(B, T, Lc)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2 * B,), 777, dtype=torch.int64)
+    v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=4, return_routes=True)
+    torch.cuda.synchronize()
+    v1, r1 = v1.clone(), r1.clone()
+    monkeypatch.setenv("VB_BAND_UNFUSED", "1")
+    v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=4, return_routes=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r2)
+    assert torch.equal(v1, v2), describe("fused vs two-GEMM band experts", v1, v2)
+
+
 def test_full_size_properties(ctx, engines):
     """BASELINE geometry (T=752, L=80): size-independent checks - finite outputs, CFG with scale 1 equals the
     conditional-only path, padding frames beyond T never leak (Tpad masking), full-length VAE/vocoder shapes."""

@@ -28,7 +28,9 @@ __device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
     lo = f2bf(v - bf2f(hi));
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division (~10 instructions): the SwiGLU epilogues run it
+// twice per output quad in the shadow of nothing (one wave per SIMD in the fused band-expert kernel)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -372,6 +372,15 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         g.y32_in = s.y32; g.row_scale = s.ma; g.out = y; g.ldc = D;
         VB_TRY(launch_gemm(g, st));
         // band experts (frequency-MoE): expert e sees only channel band e and produces only band e
+        const bool band_unfused = getenv("VB_BAND_UNFUSED") != nullptr;       // tuning / A-B switch (tests compare both)
+        if (np == 1 && band == 192 && H % 64 == 0 && E <= 8 && 8 % E == 0 && !band_unfused) {
+            // both products in one launch, hidden kept in LDS (bf16 production mode; independent of the batch size)
+            BandFfnArgs bf;
+            bf.y = y.p; bf.ldy = D; bf.w13 = (const bf16_t*)bw.w13f; bf.w2 = (const bf16_t*)bw.w2f; bf.M = N; bf.H = H; bf.E = E;
+            bf.band = band; bf.out32 = s.h; bf.ldc32 = D; bf.gate = mod + 5 * D; bf.gate_ld = MODW; bf.T = T;
+            VB_TRY(launch_band_ffn(bf, st));
+            continue;
+        }
         g = GemmArgs();
         g.A = y.p; g.a_plane = ND; g.lda = D; g.a_koff_group = band; g.B = (const bf16_t*)bw.w13f; g.b_plane = (int64_t)E * 2 * H * band;
         g.ldb = band; g.b_group_stride = (int64_t)2 * H * band; g.M = N; g.N = 2 * H; g.K = band; g.nseg = nseg; g.ngroups = E;

@@ -16,6 +16,10 @@
 //    groups; group row ranges come from a device array written by the bucket kernel.
 #include <stdlib.h>
 
+#include <string.h>
+
+#include <type_traits>
+
 #include "kernels.h"
 
 #define BM 128
@@ -260,11 +264,16 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
-        EpiPre pre[QPT];
-        int slot_[QPT], tok_[QPT]; float scale_[QPT];
+        // (in passes of at most 8 quads per thread: loads of a pass are issued before its stores; bounds the live registers)
+        constexpr int QC = QPT > 8 ? QPT / 2 : QPT;
+        static_assert(QPT % QC == 0, "quads per thread must split evenly");
 #pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            const int idx = tid + k * NTHREADS;
+        for (int kb = 0; kb < QPT; kb += QC) {
+        EpiPre pre[QC];
+        int slot_[QC], tok_[QC]; float scale_[QC];
+#pragma unroll
+        for (int kk = 0; kk < QC; ++kk) {
+            const int k = kk, idx = tid + (kb + kk) * NTHREADS;
             const int lr = idx / QPR, cq = idx - lr * QPR;
             const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
             const int n = n0 + cq * 4;
@@ -279,13 +288,15 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
             }
         }
 #pragma unroll
-        for (int k = 0; k < QPT; ++k) {
+        for (int kk = 0; kk < QC; ++kk) {
+            const int k = kk;
             if (slot_[k] < 0) continue;
-            const int idx = tid + k * NTHREADS;
+            const int idx = tid + (kb + kk) * NTHREADS;
             const int lr = idx / QPR, cq = idx - lr * QPR;
             const float4 vv = *reinterpret_cast<const float4*>(stg + lr * PITCH + cq * 4);
             float v[4] = {vv.x, vv.y, vv.z, vv.w};
             epi_store<EPI>(p, g, slot_[k], tok_[k], scale_[k], n0 + cq * 4, v, pre[k]);
+        }
         }
     }
 }
@@ -825,8 +836,216 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
 }
 
+
+// ---- band-expert FFN, fused ------------------------------------------------------------------------------------------
+// Band-MoE "frequency" experts (vocal2music_moe.py:171-178; FeedForward flag_large_dit_moe.py:480-485): expert e sees only
+// the 192-channel band e of y and produces only band e:   z[:, band e] = W2_e . ( silu(W1_e y_e) * (W3_e y_e) ).
+// As two grouped GEMMs this wrote and re-read the [N][E*512] hidden tensor (98 MB per block evaluation) and streamed every
+// weight byte through L2->LDS at 64 flop/B (the feed that bounds these K = 192 / 512 GEMMs).  Here one
+// workgroup owns 192 tokens x one band (12032 tokens x 4 bands = 252 workgroups = one round of the 256 CUs):
+//   * the token tile's band y_e [192 x 192] is DMA'd into LDS once and stays;
+//   * the hidden dimension is walked in chunks of 64: w1/w3 rows of the chunk (interleaved, [128 x 192]) stream through a
+//     2-stage ring as three K-slabs -> acc1 [192 x 128] -> SwiGLU lane-locally -> bf16 chunk [192 x 64] into LDS as the A
+//     operand of the second product -> one slab of w2 [192 x 64] -> acc2 [192 x 192] += ...   (171 flop per byte DMA'd);
+//   * the gated residual epilogue of the unfused w2 GEMM is reused as is (staged_epilogue<EPI_RESID_GATE>).
+// bf16 (np = 1) only: the split-precision parity mode keeps the two-GEMM path.
 static unsigned long long* g_gemm_trace = nullptr;
 extern "C" void vbdbg_gemm_trace(void* buf) { g_gemm_trace = static_cast<unsigned long long*>(buf); }   // tuning tool hook, not ABI
+
+struct BandDev {
+    GemmDev ep;                    // epilogue view: out32/ldc32, gate/gate_ld, T/rT, c_noff_group = band, N = band
+    const bf16_t* Y; int ldy;      // [M][ldy], band e at column e * 192
+    const bf16_t* W13; const bf16_t* W2;   // [E][2H][192] (w1/w3 rows interleaved), [E][192][H]
+    int M, H, E;
+};
+#define BF_BM 192
+#define BF_BAND 192
+__global__ void __launch_bounds__(NTHREADS) band_ffn_kernel(const BandDev p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bl[];
+    constexpr int HCH = BF_BM * 128;              // bytes of the [192 x 64] bf16 hidden chunk
+    constexpr int NSLOT = 8;                      // ring slots of 16 KB
+    unsigned char* Hs = bl;
+    unsigned char* ring = bl + HCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 31, fk = lane >> 5;
+    // XCD x handles band x % E (the band's 590 KB of weights stay in that XCD's L2), two XCDs per band at E = 4
+    const int L = blockIdx.x;
+    const int e = (L & 7) % p.E;
+    const int rt = (L >> 3) * (8 / p.E) + (L & 7) / p.E;
+    const int row0 = rt * BF_BM;
+    if (row0 >= p.M) return;
+    const int rows_end = p.M;
+    const int r8 = lane >> 3, cs = lane & 7;
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0;
+    if (p.ep.trace) tq0 = __builtin_amdgcn_s_memtime();
+
+    // The token tile's band y_e [192 x 192] is this workgroup's A operand for the whole first product: every wave keeps the
+    // fragments of its 96 rows in registers (3 row tiles x 12 k-steps x 16 B per lane = 144 VGPRs, loaded once), which leaves
+    // the LDS to the weight stream.
+    bf16x8 ay[3][12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int row = row0 + wr * 96 + i * 32 + frow;
+        if (row >= rows_end) row = row0;
+        const bf16_t* src = p.Y + (int64_t)row * p.ldy + e * BF_BAND + fk * 8;
+#pragma unroll
+        for (int kk = 0; kk < 12; ++kk) ay[i][kk] = *reinterpret_cast<const bf16x8*>(src + kk * 16);
+    }
+    const bf16_t* w13 = p.W13 + (int64_t)e * 2 * p.H * BF_BAND;
+    const bf16_t* w2 = p.W2 + (int64_t)e * BF_BAND * p.H;
+    // weight stream: per hidden chunk 5 loads - three K-slabs of w13 [128 x 64] (16 KB, 4 DMA pieces per wave) and two K-halves
+    // of the w2 slab [192 x 32] (12 KB, 3 pieces per wave) - through a ring of eight 16-KB slots, SEVEN loads ahead of the one
+    // being multiplied.  A load is 18-24 MFMAs of work per wave (0.4 us) against a ~2.3 us L2 round trip: the stream rate is
+    // (bytes in flight) / latency, so one-ahead double buffering ran at 69 us per launch and three-ahead at 59; the waits are
+    // counted vmcnt, never a drain.
+    int a_off[4], b_off[3];          // element offsets of this lane's DMA pieces inside a w13 slab / a w2 half-slab
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * (wave * 4 + i) + r8;
+        a_off[i] = r * BF_BAND + ((cs ^ ((r >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = 16 * (wave * 3 + i) + (lane >> 2);
+        b_off[i] = r * p.H + (((lane & 3) ^ ((r >> 2) & 3)) << 3);
+    }
+    const int nchunk = p.H / 64;
+    const int nload = nchunk * 5;
+    auto issue = [&](int q) {
+        unsigned char* dst = ring + (q & (NSLOT - 1)) * 16384;
+        while (q >= nload) q -= 5;                // past the end: reload the same-typed piece of the last chunk into a dead slot, so
+                                                  // every step sees the piece counts its counted vmcnt assumes
+        const int hc = q / 5, t = q - hc * 5;
+        if (t < 3) {
+            const bf16_t* src = w13 + (int64_t)hc * 128 * BF_BAND + t * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + a_off[i]), (lds_ptr_t)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        } else {
+            const bf16_t* src = w2 + hc * 64 + (t - 3) * 32;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + b_off[i]), (lds_ptr_t)(dst + (wave * 3 + i) * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < NSLOT - 1; ++q) issue(q);
+
+    f32x16 acc1[3][2], acc2[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
+    // step q multiplies load q; loads q+1 .. q+6 (already issued) may stay in flight: AHEAD = their DMA pieces per wave
+    auto step_begin = [&](int q, auto ahead) -> const unsigned char* {
+        wait_vmcnt<decltype(ahead)::value>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // own LDS writes (SwiGLU chunk) done before the barrier publishes them
+        __builtin_amdgcn_s_barrier();             // load q landed everywhere; everyone is done with load q-1's slot
+        issue(q + NSLOT - 1);                     // -> slot (q-1) % NSLOT
+        return ring + (q & (NSLOT - 1)) * 16384;
+    };
+    auto phase_a = [&](int kc, const unsigned char* Bs) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<64>(wc * 64 + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], ay[i][kc * 4 + ks], acc1[i][j], 0, 0, 0);
+        }
+    };
+    auto phase_b = [&](const unsigned char* Bs, int khalf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3], bf[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Hs + lds_off_t<64>(wr * 96 + i * 32 + frow, (khalf * 2 + ks) * 2 + fk));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<32>(wc * 96 + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc2[i][j], 0, 0, 0);
+        }
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int hc = 0; hc < nchunk; ++hc) {
+        const int q0 = hc * 5;
+        // piece counts per wave of the six loads behind the consumed one (pattern A4 A4 A4 B3 B3, cyclic)
+        const unsigned char* b0 = step_begin(q0 + 0, integral_constant<int, 22>());
+        if (hc == 0 && p.ep.trace) tq1 = __builtin_amdgcn_s_memtime();
+        phase_a(0, b0);
+        phase_a(1, step_begin(q0 + 1, integral_constant<int, 22>()));
+        phase_a(2, step_begin(q0 + 2, integral_constant<int, 21>()));
+        {
+            // SwiGLU on the interleaved (w1, w3) column pairs -> this chunk's hidden values, bf16, as the next A operand
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = wr * 96 + i * 32 + frow;
+                        const int h0 = wc * 32 + j * 16 + q * 4 + fk * 2;
+                        bf16x2 hv;
+                        hv[0] = f2bf(silu_f(acc1[i][j][q * 4 + 0]) * acc1[i][j][q * 4 + 1]);
+                        hv[1] = f2bf(silu_f(acc1[i][j][q * 4 + 2]) * acc1[i][j][q * 4 + 3]);
+                        *reinterpret_cast<bf16x2*>(Hs + lds_off_t<64>(row, h0 >> 3) + (h0 & 7) * 2) = hv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc1[i][j][q * 4 + r] = 0.f;
+                    }
+        }
+        phase_b(step_begin(q0 + 3, integral_constant<int, 21>()), 0);
+        phase_b(step_begin(q0 + 4, integral_constant<int, 22>()), 1);
+    }
+    wait_vmcnt<0>();                              // the dummy tail loads
+    if (p.ep.trace) tq2 = __builtin_amdgcn_s_memtime();
+    // gated residual: h[:, band e] += gate * z   (same epilogue as the unfused w2 GEMM; LDS is free now)
+    staged_epilogue<EPI_RESID_GATE, 3, 3>(p.ep, e, acc2, reinterpret_cast<float*>(bl), row0, rows_end, 0, tid, wr, wc, frow, fk);
+    if (p.ep.trace && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* tr = p.ep.trace + (size_t)blockIdx.x * 4;
+        tr[0] = tq0; tr[1] = tq1; tr[2] = tq2; tr[3] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
+    if (a.band != BF_BAND || a.H % 64 || (8 % a.E) || a.E > 8) VB_FAIL(VB_E_INVALID, "band_ffn: band=%d H=%d E=%d unsupported", a.band, a.H, a.E);
+    BandDev d;
+    memset(&d, 0, sizeof(d));
+    d.Y = a.y; d.ldy = a.ldy; d.W13 = a.w13; d.W2 = a.w2; d.M = a.M; d.H = a.H; d.E = a.E;
+    d.ep.out32 = a.out32; d.ep.ldc32 = a.ldc32; d.ep.gate = a.gate; d.ep.gate_ld = a.gate_ld; d.ep.T = a.T > 0 ? a.T : 1;
+    d.ep.rT = 1.0f / (float)d.ep.T; d.ep.rhd = 1.f; d.ep.rD = 1.f; d.ep.hd = 1; d.ep.D = 1;
+    d.ep.c_noff_group = a.band; d.ep.N = a.band; d.ep.M = a.M; d.ep.trace = g_gemm_trace;
+    if (a.M >= (1 << 21)) VB_FAIL(VB_E_INVALID, "band_ffn: M exceeds fdiv()");
+    const int row_tiles = cdiv(a.M, BF_BM);
+    const int per8 = 8 / a.E;                         // row tiles per group of 8 consecutive blocks
+    const int nblk = cdiv(row_tiles, per8) * 8;
+    constexpr size_t lds = (size_t)BF_BM * 128 + 8 * 16384;   // hidden chunk (24 KB) + 8 ring slots of 16 KB = 152 KB
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    ProfScope prof(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H), st);
+    hipLaunchKernelGGL(band_ffn_kernel, dim3(nblk), dim3(NTHREADS), lds, st, d);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return VB_OK;

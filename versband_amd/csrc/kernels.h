@@ -38,6 +38,14 @@ struct GemmArgs {
     int H = 1, hd = 1, Tpad = 0, D = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+// fused band-expert FFN (bf16): out32[:, e*band .. ] += gate * ( W2_e . (silu(W1_e y_e) * (W3_e y_e)) ), y_e = y[:, e*band ..]
+struct BandFfnArgs {
+    const bf16_t* y = nullptr; int ldy = 0;          // [M][ldy] bf16 (one plane)
+    const bf16_t* w13 = nullptr; const bf16_t* w2 = nullptr;   // [E][2H][band] interleaved w1/w3 rows, [E][band][H]
+    int M = 0, H = 0, E = 0, band = 0;
+    float* out32 = nullptr; int ldc32 = 0; const float* gate = nullptr; int gate_ld = 0; int T = 1;
+};
+int launch_band_ffn(const BandFfnArgs& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // flash attention over bf16 planes (head_dim 96): out = softmax(q k^T s) v  [+ w_h * softmax(q ky^T s) vy]
