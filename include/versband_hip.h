@@ -85,6 +85,8 @@ typedef struct {
     const float* t_freq_table;       /* [1000][256] sinusoid table (TimestepEmbedder.timestep_embedding) */
     const float* t_mlp0_w; const float* t_mlp0_b; const float* t_mlp2_w; const float* t_mlp2_b;
     const float* adaln_w; const float* adaln_b;   /* stacked [depth*6D + 2D][D]: blocks' adaLN then final_layer's */
+    const void* adaln_wp;                         /* optional: the same matrix as split-bf16 planes [2][rows][D]; lets the sampler tabulate
+                                                     all steps' modulations with one bf16x3 MFMA GEMM instead of an fp32 row-linear */
     const float* hl_w; const float* hl_b;         /* stacked high_level_gating_network [depth*2][D] */
     const float* proj_in_w; const float* proj_in_b;  /* conv packed [5][C][D] */
     const void* proj_in_w3;                          /* same weights as split-bf16 planes [2][5][D][32] (bf16x3 conv kernel) */

@@ -355,6 +355,70 @@ def gen_hifigan(T=8):
         print("hifigan", tag, wav.shape, float(wav.abs().max()))
 
 
+def digest(a, n_samples=32):
+    """Size-independent fingerprint of a tensor: shape, sum, L2, max-abs and n_samples elements at fixed strided positions."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    idx = (np.arange(n_samples, dtype=np.int64) * 2654435761 + 12345) % a.size
+    return {"shape_numel": np.array([a.size], dtype=np.int64), "sum": np.array([a.sum()]), "l2": np.array([np.sqrt((a * a).sum())]),
+            "maxabs": np.array([np.abs(a).max()]), "idx": idx, "val": a[idx]}
+
+
+def gen_fullsize():
+    """BASELINE geometry (one 20 s clip: T = 752, L = 80, T_mel = 1504) through the REFERENCE's own modules; only digests are
+    committed (sum / L2 / max / 32 sampled elements per tensor) - they catch size-dependent bugs the tiny goldens cannot."""
+    from ldm.models.autoencoder1d import AutoencoderKL
+    from ldm.modules.diffusionmodules.vocal2music_moe import TxtFlagLargeImprovedDiTV2
+    out = {}
+    B, T, L, E = 1, 752, 80, 4
+    cfg = synth.DiTConfig(num_experts=E)
+    net = TxtFlagLargeImprovedDiTV2(in_channels=cfg.in_channels, context_dim=cfg.context_dim, hidden_size=cfg.hidden_size,
+                                    depth=cfg.depth, num_heads=cfg.num_heads, max_len=cfg.max_len, num_experts=E,
+                                    ori_dim=cfg.ori_dim).eval()
+    net.load_state_dict(synth.make_state_dict(synth.dit_shapes(cfg), SEED), strict=True)
+    inp = clip_batch(B, T, L)
+    t_idx = torch.tensor([583] * B, dtype=torch.long)
+    nq = NoiseQueue()
+    for blk in block_noise(B, T, E, nfe=0, depth=cfg.depth):
+        for a in blk:
+            nq.push(a)
+    ctx = {"c_concat": {"midi": inp["midi"], "beats": inp["beats"]}, "c_crossattn": inp["t5_cond"], "name": ["x"] * B}
+    with torch.no_grad():
+        v, _ = net(inp["x_latent"], t_idx, ctx)
+    assert len(nq.q) == 0
+    nq.restore()
+    for k, val in digest(v.numpy()).items():
+        out["dit_v_" + k] = val
+    out["dit_t_idx"] = t_idx.numpy()
+    # VAE decode of a full-length latent, HiFi-GAN of the resulting mel
+    vcfg = synth.VAEConfig()
+    dd = dict(double_z=True, in_channels=80, out_ch=80, z_channels=20, kernel_size=5, ch=384, ch_mult=[1, 2, 4],
+              num_res_blocks=2, attn_layers=[3], down_layers=[0], dropout=0.0)
+    ae = AutoencoderKL(embed_dim=20, ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}).eval()
+    ae.load_state_dict(synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1), strict=False)
+    ae.load_state_dict(synth.make_state_dict(synth.vae_encoder_shapes(vcfg), SEED + 3), strict=False)
+    z = torch.from_numpy(prng.normal(prng.key_seed(SEED, "full_z"), 20 * T).reshape(1, 20, T))
+    with torch.no_grad():
+        mel = ae.decode(z)
+        mom = ae.encode(mel).parameters
+    for k, val in digest(mel.numpy()).items():
+        out["vae_mel_" + k] = val
+    for k, val in digest(mom.numpy()).items():
+        out["vae_moments_" + k] = val
+    hg = load_by_path("ref_hifigan_modules", os.path.join(REF, "vocoder", "hifigan", "modules", "hifigan.py"))
+    hcfg = synth.HifiGanConfig()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gen = hg.HifiGanGenerator(hcfg.as_hparams()).eval()
+    gen.load_state_dict(synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2))
+    with torch.no_grad():
+        wav = gen(mel)
+    for k, val in digest(wav.numpy()).items():
+        out["voc_wav_" + k] = val
+    np.savez_compressed(os.path.join(GOLD, "fullsize_digests.npz"), **out)
+    print("fullsize", v.shape, mel.shape, mom.shape, wav.shape)
+
+
 def use_reference_paths():
     """Make `import ldm...` / `vocoder...` / `utils...` resolve to the REFERENCE: its packages have no __init__.py (namespace
     packages), so the build's same-named shim packages would win wherever they sit on sys.path.  versband_amd is already
@@ -378,6 +442,7 @@ def main():
     gen_vae_encode()
     gen_hifigan()
     gen_sampler()
+    gen_fullsize()
 
 
 if __name__ == "__main__":

@@ -71,3 +71,16 @@ def gumbel_arrays_steps(noise_steps):
 
 def have_gpu() -> bool:
     return torch.cuda.is_available()
+
+
+def check_digest(t, g, prefix, rtol):
+    """Compare a tensor with the reference digest written by oracle/gen_golden.py:digest (sum, L2, max-abs, sampled elements)."""
+    a = torch.as_tensor(t).detach().double().cpu().reshape(-1)
+    assert a.numel() == int(g[prefix + "shape_numel"][0]), (a.numel(), int(g[prefix + "shape_numel"][0]))
+    l2, mx = float(g[prefix + "l2"][0]), float(g[prefix + "maxabs"][0])
+    assert abs(float(a.norm()) - l2) <= rtol * l2, (prefix, float(a.norm()), l2)
+    assert abs(float(a.abs().max()) - mx) <= 10 * rtol * mx, (prefix, float(a.abs().max()), mx)
+    assert abs(float(a.sum()) - float(g[prefix + "sum"][0])) <= rtol * l2 * (a.numel() ** 0.5), (prefix, float(a.sum()), float(g[prefix + "sum"][0]))
+    idx = torch.from_numpy(g[prefix + "idx"])
+    err = (a[idx] - torch.from_numpy(g[prefix + "val"])).abs().max()
+    assert float(err) <= 10 * rtol * mx, (prefix, float(err), mx)

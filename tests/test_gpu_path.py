@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu
-from tests.helpers import SEED, clip_batch, describe, exp_noise, gumbel_arrays, gumbel_arrays_steps, rel_l2
+from tests.helpers import SEED, check_digest, clip_batch, describe, exp_noise, gumbel_arrays, gumbel_arrays_steps, rel_l2
 from versband_amd import model as vm
 from versband_amd import synth
 
@@ -290,6 +290,29 @@ def test_fused_band_experts_match_two_gemm_path(engines, monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(r1, r2)
     assert torch.equal(v1, v2), describe("fused vs two-GEMM band experts", v1, v2)
+
+
+def test_fullsize_reference_digests(ctx, engines):
+    """BASELINE geometry (one 20 s clip: T = 752, L = 80, T_mel = 1504) against digests of the REFERENCE's own outputs
+    (tests/golden/fullsize_digests.npz): DiT forward in split precision on injected noise, VAE decode, VAE encode, HiFi-GAN."""
+    from versband_amd.engine import build_hifigan, build_vae_decoder, build_vae_encoder
+    g = np.load(os.path.join(GOLD, "fullsize_digests.npz"))
+    B, T, Lc, E = 1, 752, 80, 4
+    inp = clip_batch(B, T, Lc)
+    eng = engines[(E, "split")]
+    cond = eng.precompute_cond(inp["t5_cond"], inp["midi"], inp["beats"], T)
+    v = eng.forward(inp["x_latent"], torch.from_numpy(g["dit_t_idx"]), cond, noise=gumbel_arrays([exp_noise(B, T, E, 0, 4)]))
+    torch.cuda.synchronize()
+    check_digest(v, g, "dit_v_", 1e-4)
+    vcfg, hcfg = synth.VAEConfig(), synth.HifiGanConfig()
+    z = torch.from_numpy(synth.prng.normal(synth.prng.key_seed(SEED, "full_z"), 20 * T).reshape(1, 20, T))
+    mel = build_vae_decoder(ctx, synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1)).run(z)
+    check_digest(mel, g, "vae_mel_", 2e-4)
+    mom = build_vae_encoder(ctx, synth.make_state_dict(synth.vae_encoder_shapes(vcfg), SEED + 3)).run(mel)
+    check_digest(mom, g, "vae_moments_", 4e-4)
+    wav = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams()).run(mel)
+    torch.cuda.synchronize()
+    check_digest(wav, g, "voc_wav_", 1e-3)
 
 
 def test_full_size_properties(ctx, engines):

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import ref_cpu
+from tests.helpers import check_digest, clip_batch, exp_noise
 from versband_amd import synth
 
 SEED = 1234
@@ -110,3 +111,23 @@ def test_router_top1_tie_break_and_weight():
     idx, w = ref_cpu.router_top1(logits, torch.zeros_like(logits))
     assert idx.tolist() == [0, 1]
     assert torch.allclose(w, torch.ones(2), atol=2e-7)
+
+
+def test_fullsize_digests_match_reference(golden_dir, dit_sd):
+    """BASELINE geometry (T = 752, L = 80, T_mel = 1504): the oracle against digests of the reference's own outputs."""
+    g = _load(golden_dir, "fullsize_digests.npz")
+    B, T, Lc, E = 1, 752, 80, 4
+    inp = clip_batch(B, T, Lc)
+    sd = dit_sd[E]
+    cond = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
+    v = ref_cpu.dit_forward(sd, inp["x_latent"], torch.from_numpy(g["dit_t_idx"]), cond, exp_noise(B, T, E, 0, 4))
+    check_digest(v, g, "dit_v_", 5e-6)
+    vcfg = synth.VAEConfig()
+    z = torch.from_numpy(synth.prng.normal(synth.prng.key_seed(SEED, "full_z"), 20 * T).reshape(1, 20, T))
+    mel = ref_cpu.vae_decode(synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1), z)
+    check_digest(mel, g, "vae_mel_", 5e-6)
+    mom = ref_cpu.vae_encode(synth.make_state_dict(synth.vae_encoder_shapes(vcfg), SEED + 3), mel)
+    check_digest(mom, g, "vae_moments_", 5e-6)
+    hcfg = synth.HifiGanConfig()
+    wav = ref_cpu.hifigan_forward(synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), mel)
+    check_digest(wav, g, "voc_wav_", 2e-5)

@@ -704,6 +704,36 @@ int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, 
     return VB_OK;
 }
 
+// A operand of the adaLN tabulation GEMM: row (step, sample) = silu(temb[step] + cemb[sample]) as split-bf16 planes
+__global__ void __launch_bounds__(256) silu_sum_planes_kernel(const float* __restrict__ temb, const float* __restrict__ cemb, int rows,
+                                                             int D, int nsample, bf16_t* out, int64_t plane) {
+    const int64_t total = (int64_t)rows * (D / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / (D / 4)), k = (int)(i - (int64_t)r * (D / 4)) * 4;
+        const int step = r / nsample, smp = r - step * nsample;
+        const float4 a = *reinterpret_cast<const float4*>(temb + (int64_t)step * D + k);
+        const float4 b = *reinterpret_cast<const float4*>(cemb + (int64_t)smp * D + k);
+        float v[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sv = v[e] / (1.f + expf(-v[e]));          // same expression as the row-linear kernel's input activation
+            hi[e] = f2bf(sv);
+            lo[e] = f2bf(sv - bf2f(hi[e]));
+        }
+        *reinterpret_cast<bf16x4*>(out + (int64_t)r * D + k) = hi;
+        *reinterpret_cast<bf16x4*>(out + plane + (int64_t)r * D + k) = lo;
+    }
+}
+int launch_silu_sum_planes(const float* temb, const float* cemb, int rows, int D, int nsample, bf16_t* out, int64_t plane, hipStream_t st) {
+    if (D % 4) VB_FAIL(VB_E_INVALID, "silu_sum_planes: D %% 4");
+    int64_t blocks = ((int64_t)rows * (D / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_sum_planes_kernel, dim3((int)blocks), dim3(256), 0, st, temb, cemb, rows, D, nsample, out, plane);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // GroupNorm affine (+ swish) applied once, for the wide VAE layers: the conv kernels can fuse it into their staging, but a
 // layer with Co/128 output-channel tiles would then redo the exp/div of every input element Co/128 times
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,

@@ -114,6 +114,7 @@ int launch_layernorm(const float* x, const float* w, const float* b, int rows, i
                      hipStream_t st);
 int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st);
 // f32 [rows][cols] -> split-bf16 planes [2][rows][cpad] (cpad % 4 == 0, columns >= cols zero filled)
+int launch_silu_sum_planes(const float* temb, const float* cemb, int rows, int D, int nsample, bf16_t* out, int64_t plane, hipStream_t st);
 int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
                     int groups, int swish, float* out, hipStream_t st);
 int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st);

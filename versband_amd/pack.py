@@ -96,6 +96,7 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
                                + [g("final_layer.adaLN_modulation.1.weight")]).contiguous()
     top["adaln_b"] = torch.cat([g(f"blocks.{i}.adaLN_modulation.1.bias") for i in range(cfg.depth)]
                                + [g("final_layer.adaLN_modulation.1.bias")]).contiguous()
+    top["adaln_wp"] = to_planes(top["adaln_w"], 2)
     top["hl_w"] = torch.cat([g(f"blocks.{i}.feed_forward.high_level_gating_network.weight") for i in range(cfg.depth)]).contiguous()
     top["hl_b"] = torch.cat([g(f"blocks.{i}.feed_forward.high_level_gating_network.bias") for i in range(cfg.depth)]).contiguous()
     top["proj_in_w"], top["proj_in_b"] = pack_conv(g("proj_in.weight")), g("proj_in.bias")
