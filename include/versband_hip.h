@@ -91,6 +91,7 @@ typedef struct {
     const float* proj_in_w; const float* proj_in_b;  /* conv packed [5][C][D] */
     const void* proj_in_w3;                          /* same weights as split-bf16 planes [2][5][D][32] (bf16x3 conv kernel) */
     const float* final_w; const float* final_b;      /* final_layer.linear [C][D] */
+    const void* final_wp;                            /* optional: final_layer.linear as split-bf16 planes [2][C][D] (FinalLayer on the MFMA GEMM) */
     const float* rope_cos; const float* rope_sin;    /* [max_len][hd/2]  precompute_freqs_cis */
     /* precompute only */
     const float* midi_emb; const float* beats_emb;

@@ -704,6 +704,58 @@ int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, 
     return VB_OK;
 }
 
+// FinalLayer input: LayerNorm without affine (eps) then adaLN modulate, as split-bf16 planes; one wave per row, the row
+// (D <= 1024) lives in registers between the two reductions
+__global__ void __launch_bounds__(256) layernorm_mod_planes_kernel(const float* __restrict__ h, const float* __restrict__ shift,
+                                                                  const float* __restrict__ scale, int mod_ld, int rows, int D, int T,
+                                                                  float eps, Planes out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* x = h + (int64_t)row * D;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i * 256;
+        v[i] = k < D ? *reinterpret_cast<const float4*>(x + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i * 256;
+        if (k < D) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    const int b = row / T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane * 4 + i * 256;
+        if (k >= D) continue;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * mod_ld + k);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + (int64_t)b * mod_ld + k);
+        const float o[4] = {(v[i].x - mean) * rs * (1.f + sc.x) + sh.x, (v[i].y - mean) * rs * (1.f + sc.y) + sh.y,
+                            (v[i].z - mean) * rs * (1.f + sc.z) + sh.z, (v[i].w - mean) * rs * (1.f + sc.w) + sh.w};
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = f2bf(o[e]); lo[e] = f2bf(o[e] - bf2f(hi[e])); }
+        *reinterpret_cast<bf16x4*>(out.p + (int64_t)row * D + k) = hi;
+        if (out.np == 2) *reinterpret_cast<bf16x4*>(out.p + out.plane + (int64_t)row * D + k) = lo;
+    }
+}
+int launch_layernorm_mod_planes(const float* h, const float* shift, const float* scale, int mod_ld, int rows, int D, int T, float eps,
+                                Planes out, hipStream_t st) {
+    if (D % 4 || D > 1024) VB_FAIL(VB_E_INVALID, "layernorm_mod_planes: D=%d", D);
+    hipLaunchKernelGGL(layernorm_mod_planes_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, shift, scale, mod_ld, rows, D, T > 0 ? T : 1, eps, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // A operand of the adaLN tabulation GEMM: row (step, sample) = silu(temb[step] + cemb[sample]) as split-bf16 planes
 __global__ void __launch_bounds__(256) silu_sum_planes_kernel(const float* __restrict__ temb, const float* __restrict__ cemb, int rows,
                                                              int D, int nsample, bf16_t* out, int64_t plane) {

@@ -396,7 +396,18 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     }
     // ---- FinalLayer (vocal2music_moe.py:287-291) -> v [Beff][C][T]
     const float* modf = mod_all + (size_t)c.depth * 6 * D;
-    VB_TRY(launch_final_layer(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, v_out, st));
+    if (w.final_wp && c.in_channels % 4 == 0 && (int64_t)2 * N * H >= ND) {
+        // LN + modulate -> split planes (plane 0 in u, plane 1 in the free expert-hidden buffer), then the projection on the MFMA
+        // GEMM in split precision (fp32-class in both modes) with a channel-major epilogue: 62 us -> ~35 us per evaluation
+        Planes ln{s.u, (int64_t)(s.Hs - s.u), 2};
+        VB_TRY(launch_layernorm_mod_planes(s.h, modf, modf + D, MODW, N, D, T, 1e-6f, ln, st));
+        GemmArgs g;
+        g.A = ln.p; g.a_plane = ln.plane; g.lda = D; g.B = (const bf16_t*)w.final_wp; g.b_plane = (int64_t)c.in_channels * D; g.ldb = D;
+        g.M = N; g.N = c.in_channels; g.K = D; g.nseg = 3; g.epi = EPI_F32_CT; g.bias = w.final_b; g.out32 = v_out; g.T = T;
+        VB_TRY(launch_gemm(g, st));
+    } else {
+        VB_TRY(launch_final_layer(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, v_out, st));
+    }
     return VB_OK;
 }
 

@@ -74,7 +74,7 @@ struct EpiPre { float4 a, b; };
 template <int EPI>
 __device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok, int n, EpiPre& e) {
     e.a = make_float4(0.f, 0.f, 0.f, 0.f); e.b = e.a;
-    if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T) {
+    if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T || EPI == EPI_F32_CT) {
         if (p.bias) e.a = *reinterpret_cast<const float4*>(p.bias + g * p.bias_group_stride + n);
     } else if constexpr (EPI == EPI_RESID_GATE) {
         const int col = g * p.c_noff_group + n;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
     // The arithmetic is pinned (no implicit contraction, explicit fmaf): the launcher picks the tile configuration from the
     // problem size, and a clip's result must not depend on the batch it rides in - every kernel variant has to round alike.
 #pragma clang fp contract(off)
-    if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T) {
+    if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T || EPI == EPI_F32_CT) {
         v[0] += e.a.x; v[1] += e.a.y; v[2] += e.a.z; v[3] += e.a.w;
     }
     if constexpr (EPI == EPI_PLANES) {
@@ -110,6 +110,10 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         store4p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + n, v);
     } else if constexpr (EPI == EPI_F32) {
         *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_F32_CT) {
+        const int b = fdiv(m, p.rT), t = m - b * p.T;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p.out32[((int64_t)b * p.N + n + i) * p.T + t] = v[i];
     } else if constexpr (EPI == EPI_RESID_GATE) {
         const int col = g * p.c_noff_group + n;
         float4 h;
@@ -1106,6 +1110,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         VB_GEMM_CASE(EPI_SCATTER_ADD_PLANES)
         VB_GEMM_CASE(EPI_GELU_PLANES)
         VB_GEMM_CASE(EPI_HEADS_T)
+        VB_GEMM_CASE(EPI_F32_CT)
         default: VB_FAIL(VB_E_INVALID, "gemm: bad epilogue %d", a.epi);
     }
 #undef VB_GEMM_CASE

@@ -15,6 +15,7 @@ enum GemmEpi {
     EPI_SCATTER_ADD_PLANES = 6,  // planes[tok][n] = y32_in[tok][n] + row_scale[tok]*v
     EPI_GELU_PLANES = 7,     // planes = gelu_erf(v + bias)
     EPI_HEADS_T = 8,         // planes[((b*H+h)*hd+d)*Tpad + t] = v (+bias),  m = b*T+t, n = h*hd+d
+    EPI_F32_CT = 9,          // out32[(b*N + n)*T + t] = v + bias  (channel-major [B][N][T] output of the FinalLayer), m = b*T+t
     EPI_COUNT = 9
 };
 
@@ -115,6 +116,9 @@ int launch_layernorm(const float* x, const float* w, const float* b, int rows, i
 int launch_cast_planes(const float* x, int64_t n, Planes out, hipStream_t st);
 // f32 [rows][cols] -> split-bf16 planes [2][rows][cpad] (cpad % 4 == 0, columns >= cols zero filled)
 int launch_silu_sum_planes(const float* temb, const float* cemb, int rows, int D, int nsample, bf16_t* out, int64_t plane, hipStream_t st);
+// LayerNorm (no affine, eps) + adaLN modulate -> split-bf16 planes (FinalLayer input, vocal2music_moe.py:287-291)
+int launch_layernorm_mod_planes(const float* h, const float* shift, const float* scale, int mod_ld, int rows, int D, int T, float eps,
+                                Planes out, hipStream_t st);
 int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
                     int groups, int swish, float* out, hipStream_t st);
 int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st);

@@ -102,6 +102,7 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
     top["proj_in_w"], top["proj_in_b"] = pack_conv(g("proj_in.weight")), g("proj_in.bias")
     top["proj_in_w3"] = pack_conv_x3(top["proj_in_w"])[0]
     top["final_w"], top["final_b"] = g("final_layer.linear.weight"), g("final_layer.linear.bias")
+    top["final_wp"] = to_planes(top["final_w"], 2)
     cos, sin = rope_tables(cfg.head_dim, cfg.max_len)
     top["rope_cos"], top["rope_sin"] = cos.to(device), sin.to(device)
     top["midi_emb"], top["beats_emb"] = g("midi_embedding.weight"), g("beats_embedding.weight")
