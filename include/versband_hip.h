@@ -72,8 +72,11 @@ typedef struct {
     const void* wvy;    /* attention.wv_y */
     const void* wk_m;   /* MoE.cross_attention in_proj rows D:2D (precompute only) */
     const void* wv_m;   /* rows 2D:3D */
+    const void* wqt_s;  /* optional (2 planes): (in_proj rows 0:D)^T * hd^-1/2, [D in][D out] - folds the MoE q-projection into the
+                           per-clip caption keys so the gate scores come from ONE grouped GEMM (precompute only) */
     /* fp32 */
     const float* bq_m; const float* bo_m; const float* bk_m; const float* bv_m;
+    const float* bq_s;               /* bq_m * hd^-1/2 (with wqt_s) */
     const float* attn_norm_w; const float* ffn_norm_w; const float* y_norm_w;
     const float* cross_w;            /* tanh(attention.gate) [heads]   :401 */
     const float* wcg; const float* bcg;   /* caption_gating_network with cross_attention.out_proj folded in: Wg*Wo [E][D], Wg*bo+bg [E] */

@@ -21,8 +21,8 @@ class DitConfig(C.Structure):
                                       "ori_dim", "max_len", "np")] + [("norm_eps", c_float)]
 
 
-BLOCK_FIELDS = ["wqkv", "wo", "wq_m", "wo_m", "w13", "w2", "w13f", "w2f", "wky", "wvy", "wk_m", "wv_m",
-                "bq_m", "bo_m", "bk_m", "bv_m", "attn_norm_w", "ffn_norm_w", "y_norm_w", "cross_w", "wcg", "bcg", "wag", "bag"]
+BLOCK_FIELDS = ["wqkv", "wo", "wq_m", "wo_m", "w13", "w2", "w13f", "w2f", "wky", "wvy", "wk_m", "wv_m", "wqt_s",
+                "bq_m", "bo_m", "bk_m", "bv_m", "bq_s", "attn_norm_w", "ffn_norm_w", "y_norm_w", "cross_w", "wcg", "bcg", "wag", "bag"]
 
 
 class DitBlockWeights(C.Structure):

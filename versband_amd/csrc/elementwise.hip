@@ -335,25 +335,79 @@ __device__ __forceinline__ float reduce_logits(const float (&part)[16], int lane
 //   torch.max) ; (m_c, m_a) = softmax(hl[b] + G1).   G* are Gumbel draws (-log Exp(1)).
 // ---------------------------------------------------------------------------
 #define RT_TPW 4      // tokens per wave
-template <int PP>     // tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, else 1
+// SC = true: "folded" caption gate.  The token features are not materialised at all: `sc` holds the token's attention
+// SCORES against its clip's caption keys for all heads ([N][NS], NS = L * Hh, column = key * Hh + head; scale, q-projection
+// and q-bias already inside - one grouped GEMM against per-clip folded keys), `Wg` holds per clip VW[key*Hh+head][e] =
+// value_row(head) . (gate weight row e restricted to the head), so   logit_e = sum_heads sum_keys softmax(scores)_key VW_e.
+template <int PP, bool SC>     // PP: tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, else 1
 __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __restrict__ Wg,
                                                     const float* __restrict__ bg, const float* __restrict__ la, int la_rows,
                                                     const float* __restrict__ hl, int hl_ld, const float* __restrict__ g1,
                                                     const float* __restrict__ g2, const float* __restrict__ g3, int N, int T, int D,
                                                     int E, int* ic, int* ia, float* mc, float* ma, float* lc_out, int B, uint64_t seed,
-                                                    int64_t clip_base, int nfe_base, const int* step, int block) {
+                                                    int64_t clip_base, int nfe_base, const int* step, int block,
+                                                    const float* __restrict__ sc, int NS, int Hh) {
     // gate weights staged once per block (every wave re-reading E*D floats per token through L1/L2 was the kernel's
     // whole cost); a wave then walks RT_TPW tokens
     extern __shared__ float rt_ws[];
-    for (int i = threadIdx.x * 4; i < E * D; i += 256 * 4) *reinterpret_cast<float4*>(rt_ws + i) = *reinterpret_cast<const float4*>(Wg + i);
-    __syncthreads();
+    if constexpr (!SC) {
+        for (int i = threadIdx.x * 4; i < E * D; i += 256 * 4) *reinterpret_cast<float4*>(rt_ws + i) = *reinterpret_cast<const float4*>(Wg + i);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RT_TPW;
     if (n0 >= N) return;
     // phase A: the RT_TPW tokens' feature loads are issued together (token features = MoE cross-attention output, bf16
     // planes; Wg/bg already contain out_proj folded in), then E partial dot products per lane and token
     float parts[RT_TPW][16];
-    {
+    if constexpr (SC) {
+        // lane owns head (lane % Hh) and the keys lane/Hh + (64/Hh) i: columns lane + 64 i (coalesced)
+        const int kpl = NS >> 6;                       // columns per lane (<= 16)
+        float sv[RT_TPW][16];
+#pragma unroll
+        for (int tok = 0; tok < RT_TPW; ++tok) {
+            const float* srow = sc + (int64_t)min(n0 + tok, N - 1) * NS + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sv[tok][i] = i < kpl ? srow[64 * i] : -INFINITY;
+        }
+#pragma unroll
+        for (int tok = 0; tok < RT_TPW; ++tok) {
+            const int bclip = min(n0 + tok, N - 1) / T;
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, sv[tok][i]);
+            for (int o = Hh; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sv[tok][i] = i < kpl ? __expf(sv[tok][i] - m) : 0.f; l += sv[tok][i]; }
+            for (int o = Hh; o < 64; o <<= 1) l += __shfl_xor(l, o, 64);
+            const float inv = 1.f / l;
+            const float* vwb = Wg + ((int64_t)bclip * NS + lane) * E;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) parts[tok][e] = 0.f;
+            if (E == 4) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < kpl) {
+                        const float4 w = *reinterpret_cast<const float4*>(vwb + (int64_t)64 * i * 4);
+                        acc.x += sv[tok][i] * w.x; acc.y += sv[tok][i] * w.y; acc.z += sv[tok][i] * w.z; acc.w += sv[tok][i] * w.w;
+                    }
+                parts[tok][0] = acc.x * inv; parts[tok][1] = acc.y * inv; parts[tok][2] = acc.z * inv; parts[tok][3] = acc.w * inv;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float acc = 0.f;
+                    if (e < E) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (i < kpl) acc += sv[tok][i] * vwb[(int64_t)64 * i * E + e];
+                    }
+                    parts[tok][e] = acc * inv;
+                }
+            }
+        }
+    } else {
         float xv[RT_TPW][12];      // D <= 768: 3 x 4 values per lane
 #pragma unroll
         for (int tok = 0; tok < RT_TPW; ++tok) {
@@ -469,14 +523,74 @@ __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __r
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
-                  hipStream_t st) {
+                  hipStream_t st, const float* sc, int NS, int Hh) {
+    const dim3 grid(cdiv(N, 4 * RT_TPW));
+    const int Bq = B > 0 ? B : 1;
+    if (sc) {
+        // folded caption gate: logits from attention scores + per-clip VW (see router_kernel)
+        if (NS % 64 || NS > 1024 || Hh < 1 || Hh > 64 || (Hh & (Hh - 1))) VB_FAIL(VB_E_INVALID, "router: NS=%d heads=%d unsupported", NS, Hh);
+        if (2 * E + 2 <= 16)
+            hipLaunchKernelGGL((router_kernel<4, true>), grid, dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E,
+                               ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, sc, NS, Hh);
+        else
+            hipLaunchKernelGGL((router_kernel<1, true>), grid, dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E,
+                               ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, sc, NS, Hh);
+        VB_CHECK_LAUNCH();
+        return VB_OK;
+    }
     if ((E * D) % 4 != 0 || (size_t)E * D * sizeof(float) > 64 * 1024) VB_FAIL(VB_E_INVALID, "router: E*D=%d unsupported", E * D);
     if (2 * E + 2 <= 16)
-        hipLaunchKernelGGL(router_kernel<4>, dim3(cdiv(N, 4 * RT_TPW)), dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
-                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, B > 0 ? B : 1, seed, clip_base, nfe_base, step, block);
+        hipLaunchKernelGGL((router_kernel<4, false>), grid, dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
+                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, nullptr, 0, 1);
     else
-        hipLaunchKernelGGL(router_kernel<1>, dim3(cdiv(N, 4 * RT_TPW)), dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
-                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, B > 0 ? B : 1, seed, clip_base, nfe_base, step, block);
+        hipLaunchKernelGGL((router_kernel<1, false>), grid, dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
+                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, nullptr, 0, 1);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
+// Per-clip constants of the folded caption gate (once per clip and block):
+//   cbias[b][j*Hh + h] = sum_d bq_s[h*hd + d] * Kc[b][j][h*hd + d]                      (q-bias part of the scores)
+//   VW[b][j*Hh + h][e] = sum_d Vc^T[b][h][d][j] * Wcg[e][h*hd + d]                      (values pre-contracted with the gate rows)
+__global__ void __launch_bounds__(256) gate_fold_kernel(Planes kc, Planes vct, const float* __restrict__ bq_s, const float* __restrict__ wcg,
+                                                       int Beff, int L, int Lpad, int Hh, int hd, int E, float* cbias, float* vw) {
+    const int D = Hh * hd;
+    const int total = Beff * L * Hh;
+    for (int id = blockIdx.x * 256 + threadIdx.x; id < total; id += gridDim.x * 256) {
+        const int h = id % Hh, bj = id / Hh;
+        const int j = bj % L, b = bj / L;
+        const bf16_t* kr = kc.p + ((int64_t)(b * L + j)) * D + h * hd;
+        float cb = 0.f;
+        for (int d = 0; d < hd; ++d) {
+            float kv = bf2f(kr[d]);
+            if (kc.np == 2) kv += bf2f(kr[kc.plane + d]);
+            cb += bq_s[h * hd + d] * kv;
+        }
+        cbias[id] = cb;
+        const bf16_t* vr = vct.p + ((int64_t)(b * Hh + h) * hd) * Lpad + j;
+        for (int e = 0; e < E; ++e) {
+            float acc = 0.f;
+            for (int d = 0; d < hd; ++d) {
+                float vv = bf2f(vr[(int64_t)d * Lpad]);
+                if (vct.np == 2) vv += bf2f(vr[vct.plane + (int64_t)d * Lpad]);
+                acc += vv * wcg[(int64_t)e * D + h * hd + d];
+            }
+            vw[(int64_t)id * E + e] = acc;
+        }
+    }
+}
+int launch_gate_fold(Planes kc, Planes vct, const float* bq_s, const float* wcg, int Beff, int L, int Lpad, int Hh, int hd, int E,
+                     float* cbias, float* vw, hipStream_t st) {
+    hipLaunchKernelGGL(gate_fold_kernel, dim3(cdiv(Beff * L * Hh, 256)), dim3(256), 0, st, kc, vct, bq_s, wcg, Beff, L, Lpad, Hh, hd, E, cbias, vw);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+__global__ void iota_mul_kernel(int* out, int n, int mul) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = i * mul;
+}
+int launch_iota_mul(int* out, int n, int mul, hipStream_t st) {
+    hipLaunchKernelGGL(iota_mul_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, out, n, mul);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

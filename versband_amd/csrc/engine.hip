@@ -84,9 +84,16 @@ struct CondL {
     float* ac; float* cemb;
     bf16_t* ky[VB_MAX_DEPTH]; bf16_t* vyt[VB_MAX_DEPTH]; bf16_t* kc[VB_MAX_DEPTH]; bf16_t* vct[VB_MAX_DEPTH];
     float* la[VB_MAX_DEPTH];
+    // folded caption gate (see router_kernel<.., true>): per clip and block the caption keys with the MoE q-projection folded in
+    // (planes [Beff][NS = L*heads][D], row = key*heads + head), the q-bias part of the scores and the gate-contracted values
+    bf16_t* mf[VB_MAX_DEPTH]; float* cb[VB_MAX_DEPTH]; float* vw[VB_MAX_DEPTH]; int* clip_off; int NS; bool fold;
     int64_t n_k, n_vt; int Lpad;
     size_t total;
 };
+static inline bool gate_fold_ok(const vb_dit_config& c, int L) {
+    const int NS = L * c.heads;
+    return NS % 64 == 0 && NS <= 1024 && NS <= c.hidden && (c.heads & (c.heads - 1)) == 0 && c.heads <= 64 && getenv("VB_GATE_UNFOLDED") == nullptr;
+}
 static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T, int L) {
     CondL o;
     Carver cv(base);
@@ -102,6 +109,14 @@ static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T
         o.kc[i] = cv.take<bf16_t>(o.n_k * c.np);
         o.vct[i] = cv.take<bf16_t>(o.n_vt * c.np);
         o.la[i] = cv.take<float>((size_t)B * T * c.num_experts);
+    }
+    o.NS = L * c.heads;
+    o.fold = gate_fold_ok(c, L);
+    o.clip_off = cv.take<int>((size_t)Beff + 1);
+    for (int i = 0; i < c.depth; ++i) {
+        o.mf[i] = o.fold ? cv.take<bf16_t>((size_t)Beff * o.NS * D * c.np) : nullptr;
+        o.cb[i] = o.fold ? cv.take<float>((size_t)Beff * o.NS) : nullptr;
+        o.vw[i] = o.fold ? cv.take<float>((size_t)Beff * o.NS * c.num_experts) : nullptr;
     }
     o.total = cv.off;
     return o;
@@ -262,7 +277,19 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
             VB_TRY(launch_gemm(g, st));
         }
         VB_TRY(launch_rows_dot(cd.ac, bw.wag, bw.bag, B * T, D, E, cd.la[i], st));
+        if (cd.fold && bw.wqt_s && bw.bq_s) {
+            // Mf[b][key*heads + head][:] = hd^-1/2 * sum_d Kc[b][key][head*hd + d] * Wq[head*hd + d][:]   (one launch, head = grid z)
+            g = GemmArgs();
+            g.A = cd.kc[i]; g.a_plane = cd.n_k; g.lda = D; g.a_koff_group = hd;
+            g.B = (const bf16_t*)bw.wqt_s; g.b_plane = (int64_t)D * D; g.ldb = D; g.b_group_stride = hd;
+            g.M = (int)NL; g.N = D; g.K = hd; g.nseg = np == 2 ? 3 : 1; g.ngroups = c.heads;
+            g.epi = EPI_PLANES; g.out = mkp(cd.mf[i], (int64_t)Beff * cd.NS * D, np); g.ldc = c.heads * D; g.c_noff_group = D;
+            VB_TRY(launch_gemm(g, st));
+            VB_TRY(launch_gate_fold(mkp(cd.kc[i], cd.n_k, np), mkp(cd.vct[i], cd.n_vt, np), bw.bq_s, bw.wcg, Beff, L, cd.Lpad, c.heads, hd, E,
+                                    cd.cb[i], cd.vw[i], st));
+        }
     }
+    VB_TRY(launch_iota_mul(cd.clip_off, Beff + 1, T, st));
     return VB_OK;
 }
 
@@ -334,6 +361,17 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
 
         // ---- Band-MoE (vocal2music_moe.py:117-185)
         VB_TRY(launch_rmsnorm_mod(s.h, bw.ffn_norm_w, mod + 3 * D, mod + 4 * D, MODW, N, D, T, c.norm_eps, u, st));
+        const bool fold = cd.fold && bw.wqt_s && bw.bq_s;
+        if (fold) {
+            // caption gate, folded: scores of every token against its clip's caption keys for all heads in ONE grouped GEMM
+            // (q-projection, q-bias and softmax scale live in the per-clip operand), then softmax + value/gate contraction +
+            // routing in the router kernel.  Replaces q-projection GEMM + cross-attention launch + 768-wide gate dot.
+            g = GemmArgs();
+            g.A = u.p; g.a_plane = ND; g.lda = D; g.B = cd.mf[i]; g.b_plane = (int64_t)Beff * cd.NS * D; g.ldb = D;
+            g.b_group_stride = (int64_t)cd.NS * D; g.M = N; g.N = cd.NS; g.K = D; g.nseg = nseg; g.ngroups = Beff;
+            g.group_off = cd.clip_off; g.epi = EPI_F32; g.bias = cd.cb[i]; g.bias_group_stride = cd.NS; g.out32 = s.y32; g.ldc32 = cd.NS;
+            VB_TRY(launch_gemm(g, st));
+        } else {
         g = GemmArgs();
         g.A = u.p; g.a_plane = ND; g.lda = D; g.B = (const bf16_t*)bw.wq_m; g.b_plane = (int64_t)D * D; g.ldb = D;
         g.M = N; g.N = D; g.K = D; g.nseg = nseg; g.epi = EPI_PLANES; g.bias = bw.bq_m; g.out = qm; g.ldc = D;
@@ -343,6 +381,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         at.vyt = mkp(cd.vct[i], cd.n_vt, np); at.cross_w = nullptr; at.out = cqa; at.B = Beff; at.T = T; at.Tpad = s.Tpad; at.L = L;
         at.Lpad = cd.Lpad; at.H = c.heads; at.hd = hd; at.has_self = 0; at.has_cross = 1; at.kv_batch_mod = 0; at.scale = scale;
         VB_TRY(launch_attention(at, st));
+        }
         // (MoE.cross_attention.out_proj is folded into the caption gate at pack time: lc = cqa . (Wcg Wo)^T + (Wcg bo + bcg),
         //  so the [N,768]x[768,768] out_proj GEMM never runs - its only consumer is the 768->E gate, vocal2music_moe.py:119-141)
         // gates: injected Gumbel arrays (parity path) or counter-based draws generated inside the router kernel
@@ -351,8 +390,9 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
             const size_t so = (size_t)noise_step * c.depth + i;
             g1 = noise->g1 + so * N * 2; g2 = noise->g2 + so * N * E; g3 = noise->g3 + so * N * E;
         }
-        VB_TRY(launch_router(cqa, bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
-                             s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st));
+        VB_TRY(launch_router(cqa, fold ? cd.vw[i] : bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
+                             s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st,
+                             fold ? s.y32 : nullptr, cd.NS, c.heads));
         VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -138,10 +138,13 @@ int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_sca
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
-                  hipStream_t st);
+                  hipStream_t st, const float* sc = nullptr, int NS = 0, int Hh = 1);
 int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st);
 int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this many ints
+int launch_gate_fold(Planes kc, Planes vct, const float* bq_s, const float* wcg, int Beff, int L, int Lpad, int Hh, int hd, int E,
+                     float* cbias, float* vw, hipStream_t st);
+int launch_iota_mul(int* out, int n, int mul, hipStream_t st);
 int launch_router_top1(const float* logits, const float* gumbel, int N, int E, int* idx, hipStream_t st);
 int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
                        const int* step, int block, int gate, hipStream_t st);

@@ -123,6 +123,9 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
         w_in, b_in = g(p + "feed_forward.cross_attention.in_proj_weight"), g(p + "feed_forward.cross_attention.in_proj_bias")
         b["wq_m"] = to_planes(w_in[:D], n_planes)
         b["wk_m"], b["wv_m"] = to_planes(w_in[D:2 * D], 2), to_planes(w_in[2 * D:], 2)
+        qscale = float(cfg.head_dim) ** -0.5
+        b["wqt_s"] = to_planes((w_in[:D].t() * qscale).contiguous(), 2)
+        b["bq_s"] = (b_in[:D] * qscale).contiguous()
         b["bq_m"], b["bk_m"], b["bv_m"] = b_in[:D].contiguous(), b_in[D:2 * D].contiguous(), b_in[2 * D:].contiguous()
         b["wo_m"] = to_planes(g(p + "feed_forward.cross_attention.out_proj.weight"), n_planes)
         b["bo_m"] = g(p + "feed_forward.cross_attention.out_proj.bias")
