@@ -232,6 +232,7 @@ def main():
                             wav=None))
 
     def run_worker(w, ks):
+        torch.cuda.set_device(device)           # a new host thread starts on device 0: bind it to this rank's GPU
         with torch.cuda.stream(w["stream"]):
             for k in ks:
                 cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_LAT)
