@@ -468,6 +468,7 @@ static size_t net_ws_bytes(const NetProgram& n, int B, int T, std::vector<size_t
 static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float* out, void* ws, hipStream_t st) {
     NetProgram& n = ctx->nets[which];
     if (!n.loaded) VB_FAIL(VB_E_STATE, "net %d not loaded", which);
+    VB_HIP(hipSetDevice(ctx->device));
     std::vector<size_t> offs;
     net_ws_bytes(n, B, T, &offs);
     auto ptr = [&](int id) -> float* {
@@ -624,11 +625,13 @@ int vb_dit_precompute_cond(vb_ctx* ctx, const float* t5, const int64_t* midi, co
                            int T_mel, int L, void* cond, void* ws, void* stream) {
     if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "precompute_cond: DiT not loaded");
     if (n_branch < 1 || n_branch > 2 || B < 1) VB_FAIL(VB_E_INVALID, "precompute_cond: B=%d n_branch=%d", B, n_branch);
+    VB_HIP(hipSetDevice(ctx->device));
     return dit_precompute(ctx, t5, midi, beats, B, n_branch, T, T_mel, L, cond, ws, (hipStream_t)stream);
 }
 int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int B, int n_branch,
                    int T, int L, float* v_out, int32_t* route_out, void* ws, void* stream) {
     if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "dit_forward: DiT not loaded");
+    VB_HIP(hipSetDevice(ctx->device));        // the calling host thread may be new (one thread per stream): bind it to the context's GPU
     return dit_forward(ctx, x, t_idx, cond, noise, 0, nullptr, B, n_branch, T, L, v_out, route_out, ws, true, nullptr, nullptr,
                        (hipStream_t)stream);
 }
@@ -640,6 +643,7 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
                   void* stream) {
     if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "sample_cfg: DiT not loaded");
     if (n_steps < 1 || n_steps > 1024) VB_FAIL(VB_E_INVALID, "sample_cfg: n_steps=%d", n_steps);
+    VB_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const vb_dit_config& c = ctx->cfg;
     WsL s = carve_ws(ws, c, B, n_branch, T, L);
