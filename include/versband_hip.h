@@ -194,6 +194,34 @@ int vb_vae_encode(vb_ctx* ctx, const float* mel, int B, int T, float* moments, v
 /* HifiGAN.spec2wav (vocoder/hifigan/hifigan.py:20-30): mel [B][80][T] -> wav [B][T*hop] */
 int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream);
 
+/* ------------------------------------------------------------ T5 text encoder ----
+ * FrozenTextVocalEmbedder.forward (ldm/modules/encoders/modules.py:216-233): T5EncoderModel(input_ids).last_hidden_state, no
+ * attention mask.  HF T5 encoder stack (transformers T5Stack / T5Block / T5Attention / T5DenseGatedActDense / T5LayerNorm):
+ * per block  x += O(softmax(Q K^T + rel_pos_bias) V)  on RMS-normed x (no 1/sqrt(d) scaling), x += Wo(gelu_new(Wi0 n) * Wi1 n);
+ * final RMS norm.  Runs in split precision (fp32-class) on the same GEMM kernel as the DiT.  The tokenizer stays upstream. */
+#define VB_T5_MAX_LAYERS 48
+typedef struct { int vocab, d_model, d_kv, heads, d_ff, layers; float eps; } vb_t5_config;
+typedef struct {
+    const float* ln0;     /* layer.0.layer_norm.weight [d_model] */
+    const void* wqkv;     /* planes(2) [3*heads*d_kv][d_model]: q | k | v rows */
+    const void* wo;       /* planes(2) [d_model][heads*d_kv] */
+    const float* ln1;     /* layer.1.layer_norm.weight */
+    const void* wi;       /* planes(2) [2*d_ff][d_model]: rows interleaved wi_0[j], wi_1[j] */
+    const void* wo_ff;    /* planes(2) [d_model][d_ff] */
+} vb_t5_layer;
+typedef struct {
+    const float* embed;       /* shared.weight [vocab][d_model] */
+    const float* pos_bias;    /* [heads][Lmax][Lmax] relative-position bias of block 0 (shared by all blocks), built by the host */
+    int pos_len;              /* Lmax */
+    const float* final_ln;    /* encoder.final_layer_norm.weight */
+    const float* ones;        /* [d_model] ones (residual "gate") */
+    vb_t5_layer layers[VB_T5_MAX_LAYERS];
+} vb_t5_weights;
+int vb_t5_load(vb_ctx* ctx, const vb_t5_config* cfg, const vb_t5_weights* w);
+size_t vb_t5_workspace_bytes(const vb_t5_config* cfg, int B, int L);
+/* ids int64 [B][L] -> out f32 [B][L][d_model] */
+int vb_t5_encode(vb_ctx* ctx, const int64_t* ids, int B, int L, float* out, void* ws, void* stream);
+
 /* ------------------------------------------------------------------- unit kernels ---- */
 /* RMSNorm (flag_large_dit_moe.py:52-77) * w then modulate (:80-81); shift/scale [B][mod_ld] or NULL */
 int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D,

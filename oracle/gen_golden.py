@@ -419,6 +419,43 @@ def gen_fullsize():
     print("fullsize", v.shape, mel.shape, mom.shape, wav.shape)
 
 
+def gen_t5():
+    """T5 text encoder.  The reference calls transformers.T5EncoderModel (modules.py:197-221); transformers is not
+    pinned by requirements.txt - the fixtures pin the behaviour of the version installed here (recorded in the file)."""
+    import transformers
+    from transformers import T5Config, T5EncoderModel
+
+    def run(cfg, B, L, seed_tag):
+        hf = T5EncoderModel(T5Config(vocab_size=cfg.vocab_size, d_model=cfg.d_model, d_kv=cfg.d_kv, d_ff=cfg.d_ff, num_layers=cfg.num_layers,
+                                     num_heads=cfg.num_heads, relative_attention_num_buckets=cfg.relative_attention_num_buckets,
+                                     relative_attention_max_distance=cfg.relative_attention_max_distance, dropout_rate=0.0,
+                                     layer_norm_epsilon=cfg.layer_norm_epsilon, feed_forward_proj="gated-gelu", tie_word_embeddings=False)).eval()
+        sd = synth.make_state_dict(synth.t5_encoder_shapes(cfg), SEED + 5)
+        full = dict(sd)
+        full["encoder.embed_tokens.weight"] = sd["shared.weight"]
+        assert set(hf.state_dict()) == set(full), set(hf.state_dict()) ^ set(full)
+        hf.load_state_dict(full)
+        ids = torch.from_numpy((prng.uniform(prng.key_seed(SEED, seed_tag), B * L, 0.0, 1.0) * cfg.vocab_size).astype(np.int64).reshape(B, L))
+        ids = ids.clamp(0, cfg.vocab_size - 1)
+        ids[:, L - L // 4:] = 0                           # trailing pad tokens, as the tokenizer's padding="max_length" produces
+        with torch.no_grad():
+            out = hf(input_ids=ids).last_hidden_state
+        return ids, out
+
+    small = synth.T5Config(vocab_size=512, num_layers=2)
+    ids, out = run(small, 2, 80, "t5_ids_small")
+    o = {"ids": ids.numpy(), "out_slice": out[:, :, :48].numpy(), "version": np.array([int(x) for x in transformers.__version__.split(".")[:2]])}
+    for k, v in digest(out.numpy()).items():
+        o["out_" + k] = v
+    full = synth.T5Config(vocab_size=2048)                # all 24 layers at full width; only the vocabulary table is cut down
+    ids2, out2 = run(full, 1, 80, "t5_ids_full")
+    o["ids24"] = ids2.numpy()
+    for k, v in digest(out2.numpy()).items():
+        o["out24_" + k] = v
+    np.savez_compressed(os.path.join(GOLD, "t5_encode.npz"), **o)
+    print("t5", out.shape, out2.shape, float(out.abs().max()), float(out2.abs().max()))
+
+
 def use_reference_paths():
     """Make `import ldm...` / `vocoder...` / `utils...` resolve to the REFERENCE: its packages have no __init__.py (namespace
     packages), so the build's same-named shim packages would win wherever they sit on sys.path.  versband_amd is already
@@ -443,6 +480,7 @@ def main():
     gen_hifigan()
     gen_sampler()
     gen_fullsize()
+    gen_t5()
 
 
 if __name__ == "__main__":

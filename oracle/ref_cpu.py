@@ -418,6 +418,61 @@ def gaussian_posterior(moments: Tensor, noise: Tensor = None, scale_factor: floa
 
 
 # ---------------------------------------------------------------------------
+# T5 text encoder - the reference calls transformers.T5EncoderModel (ldm/modules/encoders/modules.py:197-221);
+# transformers is a third-party dependency that requirements.txt does not pin.  Restated from the published HF
+# implementation (modeling_t5.py: T5LayerNorm, T5Attention incl. _relative_position_bucket, T5DenseGatedActDense, T5Stack)
+# and pinned against the transformers installed in the build container (tests/golden/t5_encode*.npz).
+# ---------------------------------------------------------------------------
+
+
+def t5_relative_position_bucket(relative_position: Tensor, num_buckets: int = 32, max_distance: int = 128) -> Tensor:
+    """T5Attention._relative_position_bucket with bidirectional=True (encoder)."""
+    num_buckets //= 2
+    rb = (relative_position > 0).to(torch.long) * num_buckets
+    rp = torch.abs(relative_position)
+    max_exact = num_buckets // 2
+    is_small = rp < max_exact
+    large = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return rb + torch.where(is_small, rp, large)
+
+
+def t5_position_bias(rel_emb: Tensor, L: int, num_buckets: int = 32, max_distance: int = 128) -> Tensor:
+    """T5Attention.compute_bias: [heads, L, L] = embedding[bucket(key - query)]."""
+    ctx = torch.arange(L, dtype=torch.long)[:, None]
+    mem = torch.arange(L, dtype=torch.long)[None, :]
+    bucket = t5_relative_position_bucket(mem - ctx, num_buckets, max_distance)
+    return rel_emb[bucket].permute(2, 0, 1).contiguous()
+
+
+def _t5_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    return w * (x * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps))
+
+
+def t5_encode(sd: Dict[str, Tensor], ids: Tensor, num_heads: int = 16, eps: float = 1e-6, num_buckets: int = 32,
+              max_distance: int = 128) -> Tensor:
+    """T5EncoderModel(input_ids=ids).last_hidden_state, no attention mask, dropout off.  ids [B,L] -> [B,L,d_model]."""
+    x = sd["shared.weight"][ids]
+    B, L, D = x.shape
+    n_layers = len({int(k.split(".")[2]) for k in sd if k.startswith("encoder.block.")})
+    bias = t5_position_bias(sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], L, num_buckets, max_distance)
+    for i in range(n_layers):
+        p = f"encoder.block.{i}."
+        n = _t5_norm(x, sd[p + "layer.0.layer_norm.weight"], eps)
+        q = (n @ sd[p + "layer.0.SelfAttention.q.weight"].t()).view(B, L, num_heads, -1).transpose(1, 2)
+        k = (n @ sd[p + "layer.0.SelfAttention.k.weight"].t()).view(B, L, num_heads, -1).transpose(1, 2)
+        v = (n @ sd[p + "layer.0.SelfAttention.v.weight"].t()).view(B, L, num_heads, -1).transpose(1, 2)
+        sc = torch.matmul(q, k.transpose(3, 2)) + bias[None]                      # no 1/sqrt(d) in T5
+        a = torch.matmul(torch.softmax(sc.float(), dim=-1), v).transpose(1, 2).reshape(B, L, -1)
+        x = x + a @ sd[p + "layer.0.SelfAttention.o.weight"].t()
+        n = _t5_norm(x, sd[p + "layer.1.layer_norm.weight"], eps)
+        g = n @ sd[p + "layer.1.DenseReluDense.wi_0.weight"].t()
+        g = 0.5 * g * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (g + 0.044715 * torch.pow(g, 3.0))))     # NewGELUActivation
+        x = x + (g * (n @ sd[p + "layer.1.DenseReluDense.wi_1.weight"].t())) @ sd[p + "layer.1.DenseReluDense.wo.weight"].t()
+    return _t5_norm(x, sd["encoder.final_layer_norm.weight"], eps)
+
+
+# ---------------------------------------------------------------------------
 # HiFi-GAN generator
 # ---------------------------------------------------------------------------
 

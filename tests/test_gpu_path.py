@@ -315,6 +315,28 @@ def test_fullsize_reference_digests(ctx, engines):
     check_digest(wav, g, "voc_wav_", 1e-3)
 
 
+def test_t5_encoder_vs_transformers_golden_and_oracle(ctx):
+    """T5 text encoder through vb_t5_encode (split-precision GEMMs, fp32 attention with the relative-position bias)
+    against transformers.T5EncoderModel fixtures (2 layers: slice + digest, 24 layers: digest) and the oracle on a ragged length."""
+    from versband_amd.engine import T5Engine
+    g = np.load(os.path.join(GOLD, "t5_encode.npz"))
+    sd = synth.make_state_dict(synth.t5_encoder_shapes(synth.T5Config(vocab_size=512, num_layers=2)), SEED + 5)
+    enc = T5Engine(ctx, sd)
+    out = enc.encode(torch.from_numpy(g["ids"]))
+    torch.cuda.synchronize()
+    assert rel_l2(out[:, :, :48], g["out_slice"]) < 1e-4, describe("t5 vs transformers", out[:, :, :48], g["out_slice"])
+    check_digest(out, g, "out_", 1e-4)
+    ids = torch.from_numpy((synth.prng.uniform(99, 3 * 37, 0.0, 1.0) * 512).astype(np.int64).reshape(3, 37)).clamp(0, 511)
+    ref = ref_cpu.t5_encode(sd, ids)
+    out = enc.encode(ids)
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 1e-4, describe("t5 L=37 vs oracle", out, ref)
+    sd24 = synth.make_state_dict(synth.t5_encoder_shapes(synth.T5Config(vocab_size=2048)), SEED + 5)
+    out24 = T5Engine(ctx, sd24).encode(torch.from_numpy(g["ids24"]))
+    torch.cuda.synchronize()
+    check_digest(out24, g, "out24_", 3e-4)
+
+
 def test_full_size_properties(ctx, engines):
     """BASELINE geometry (T=752, L=80): size-independent checks - finite outputs, CFG with scale 1 equals the
     conditional-only path, padding frames beyond T never leak (Tpad masking), full-length VAE/vocoder shapes."""

@@ -131,3 +131,15 @@ def test_fullsize_digests_match_reference(golden_dir, dit_sd):
     hcfg = synth.HifiGanConfig()
     wav = ref_cpu.hifigan_forward(synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), mel)
     check_digest(wav, g, "voc_wav_", 2e-5)
+
+
+def test_t5_encoder_matches_transformers(golden_dir):
+    """SURVEY 8f N1: the T5 restatement against fixtures produced by transformers.T5EncoderModel (2 layers: output slice + digest;
+    all 24 layers: digest)."""
+    g = _load(golden_dir, "t5_encode.npz")
+    sd = synth.make_state_dict(synth.t5_encoder_shapes(synth.T5Config(vocab_size=512, num_layers=2)), SEED + 5)
+    out = ref_cpu.t5_encode(sd, torch.from_numpy(g["ids"]))
+    assert _rel(out[:, :, :48], g["out_slice"]) < 2e-6
+    check_digest(out, g, "out_", 5e-6)
+    sd24 = synth.make_state_dict(synth.t5_encoder_shapes(synth.T5Config(vocab_size=2048)), SEED + 5)
+    check_digest(ref_cpu.t5_encode(sd24, torch.from_numpy(g["ids24"])), g, "out24_", 2e-5)

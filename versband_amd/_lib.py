@@ -39,6 +39,23 @@ class DitWeights(C.Structure):
     _fields_ = [("blocks", DitBlockWeights * VB_MAX_DEPTH)] + [(n, c_void_p) for n in TOP_FIELDS]
 
 
+VB_T5_MAX_LAYERS = 48
+T5_LAYER_FIELDS = ["ln0", "wqkv", "wo", "ln1", "wi", "wo_ff"]
+
+
+class T5Config(C.Structure):
+    _fields_ = [(n, c_int) for n in ("vocab", "d_model", "d_kv", "heads", "d_ff", "layers")] + [("eps", c_float)]
+
+
+class T5Layer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in T5_LAYER_FIELDS]
+
+
+class T5Weights(C.Structure):
+    _fields_ = [("embed", c_void_p), ("pos_bias", c_void_p), ("pos_len", c_int), ("final_ln", c_void_p), ("ones", c_void_p),
+                ("layers", T5Layer * VB_T5_MAX_LAYERS)]
+
+
 class Noise(C.Structure):
     _fields_ = [("g1", c_void_p), ("g2", c_void_p), ("g3", c_void_p), ("seed", c_u64), ("clip_base", c_i64), ("nfe", c_int)]
 
@@ -81,6 +98,9 @@ PROTOTYPES = {
     "vb_net_workspace_bytes": (c_size_t, [P, c_int, c_int, c_int]),
     "vb_vae_decode": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_vae_encode": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_t5_load": (c_int, [P, C.POINTER(T5Config), C.POINTER(T5Weights)]),
+    "vb_t5_workspace_bytes": (C.c_size_t, [C.POINTER(T5Config), c_int, c_int]),
+    "vb_t5_encode": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_hifigan_forward": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_rmsnorm_modulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, P]),
     "vb_router_top1": (c_int, [P, P, c_int, c_int, P, P]),

@@ -61,6 +61,9 @@ struct vb_ctx {
     vb_dit_config cfg;
     vb_dit_weights w;
     NetProgram nets[3];
+    bool t5_loaded = false;
+    vb_t5_config t5cfg;
+    vb_t5_weights t5w;
 };
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -684,6 +687,72 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
         VB_TRY(launch_euler_cfg(x, s.v, B, per, cfg_scale, s.dt_table, s.step, 0.f, n_branch == 2, st));
         if (traj) VB_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * B * per, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
+    return VB_OK;
+}
+
+// ---- T5 text encoder -------------------------------------------------------------------------------
+struct T5Ws { float* h; bf16_t* nrm; bf16_t* qkv; bf16_t* att; bf16_t* ff; size_t total; };
+static T5Ws carve_t5(void* base, const vb_t5_config& c, int B, int L) {
+    T5Ws o;
+    Carver cv(base);
+    const size_t R = (size_t)B * L, inner = (size_t)c.heads * c.d_kv;
+    o.h = cv.take<float>(R * c.d_model);
+    o.nrm = cv.take<bf16_t>(2 * R * c.d_model);
+    o.qkv = cv.take<bf16_t>(2 * R * 3 * inner);
+    o.att = cv.take<bf16_t>(2 * R * inner);
+    o.ff = cv.take<bf16_t>(2 * R * c.d_ff);
+    o.total = cv.off;
+    return o;
+}
+int vb_t5_load(vb_ctx* ctx, const vb_t5_config* cfg, const vb_t5_weights* w) {
+    if (!ctx || !cfg || !w) VB_FAIL(VB_E_INVALID, "t5_load: null argument");
+    if (cfg->layers < 1 || cfg->layers > VB_T5_MAX_LAYERS) VB_FAIL(VB_E_INVALID, "t5_load: layers %d", cfg->layers);
+    if (cfg->d_kv != 64) VB_FAIL(VB_E_INVALID, "t5_load: d_kv %d unsupported (attention kernel is built for 64)", cfg->d_kv);
+    if (cfg->d_model % 64 || cfg->d_ff % 64 || cfg->d_model > 1024) VB_FAIL(VB_E_INVALID, "t5_load: d_model %d / d_ff %d", cfg->d_model, cfg->d_ff);
+    ctx->t5cfg = *cfg;
+    ctx->t5w = *w;
+    ctx->t5_loaded = true;
+    return VB_OK;
+}
+size_t vb_t5_workspace_bytes(const vb_t5_config* cfg, int B, int L) { return carve_t5(nullptr, *cfg, B, L).total; }
+int vb_t5_encode(vb_ctx* ctx, const int64_t* ids, int B, int L, float* out, void* ws, void* stream) {
+    if (!ctx || !ctx->t5_loaded) VB_FAIL(VB_E_STATE, "t5_encode: T5 not loaded");
+    VB_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const vb_t5_config& c = ctx->t5cfg;
+    const vb_t5_weights& w = ctx->t5w;
+    if (L > w.pos_len) VB_FAIL(VB_E_INVALID, "t5_encode: L=%d exceeds the position-bias table (%d)", L, w.pos_len);
+    T5Ws s = carve_t5(ws, c, B, L);
+    const int R = B * L, D = c.d_model, inner = c.heads * c.d_kv;
+    VB_TRY(launch_gather_rows(ids, w.embed, R, D, c.vocab, s.h, st));
+    Planes nrm = mkp(s.nrm, (int64_t)R * D, 2), qkv = mkp(s.qkv, (int64_t)R * 3 * inner, 2), att = mkp(s.att, (int64_t)R * inner, 2);
+    Planes ff = mkp(s.ff, (int64_t)R * c.d_ff, 2);
+    for (int i = 0; i < c.layers; ++i) {
+        const vb_t5_layer& lw = w.layers[i];
+        // x += O(softmax(Q K^T + bias) V),  Q/K/V from T5LayerNorm(x)   (T5LayerSelfAttention)
+        VB_TRY(launch_rmsnorm_mod(s.h, lw.ln0, nullptr, nullptr, 0, R, D, L, c.eps, nrm, st));
+        GemmArgs g;
+        g.A = nrm.p; g.a_plane = nrm.plane; g.lda = D; g.B = (const bf16_t*)lw.wqkv; g.b_plane = (int64_t)3 * inner * D; g.ldb = D;
+        g.M = R; g.N = 3 * inner; g.K = D; g.nseg = 3; g.epi = EPI_PLANES; g.out = qkv; g.ldc = 3 * inner;
+        VB_TRY(launch_gemm(g, st));
+        VB_TRY(launch_t5_attention(qkv, w.pos_bias, w.pos_len, B, L, c.heads, c.d_kv, att, st));
+        g = GemmArgs();
+        g.A = att.p; g.a_plane = att.plane; g.lda = inner; g.B = (const bf16_t*)lw.wo; g.b_plane = (int64_t)D * inner; g.ldb = inner;
+        g.M = R; g.N = D; g.K = inner; g.nseg = 3; g.epi = EPI_RESID_GATE; g.out32 = s.h; g.ldc32 = D; g.gate = w.ones; g.gate_ld = 0; g.T = L;
+        VB_TRY(launch_gemm(g, st));
+        // x += Wo(gelu_new(Wi0 n) * Wi1 n),  n = T5LayerNorm(x)   (T5LayerFF, gated-gelu)
+        VB_TRY(launch_rmsnorm_mod(s.h, lw.ln1, nullptr, nullptr, 0, R, D, L, c.eps, nrm, st));
+        g = GemmArgs();
+        g.A = nrm.p; g.a_plane = nrm.plane; g.lda = D; g.B = (const bf16_t*)lw.wi; g.b_plane = (int64_t)2 * c.d_ff * D; g.ldb = D;
+        g.M = R; g.N = 2 * c.d_ff; g.K = D; g.nseg = 3; g.epi = EPI_GEGLU; g.out = ff; g.ldc = c.d_ff;
+        VB_TRY(launch_gemm(g, st));
+        g = GemmArgs();
+        g.A = ff.p; g.a_plane = ff.plane; g.lda = c.d_ff; g.B = (const bf16_t*)lw.wo_ff; g.b_plane = (int64_t)D * c.d_ff; g.ldb = c.d_ff;
+        g.M = R; g.N = D; g.K = c.d_ff; g.nseg = 3; g.epi = EPI_RESID_GATE; g.out32 = s.h; g.ldc32 = D; g.gate = w.ones; g.gate_ld = 0; g.T = L;
+        VB_TRY(launch_gemm(g, st));
+    }
+    VB_TRY(launch_rmsnorm_mod(s.h, w.final_ln, nullptr, nullptr, 0, R, D, L, c.eps, nrm, st));
+    VB_TRY(launch_planes_to_f32(nrm, (int64_t)R * D, out, st));
     return VB_OK;
 }
 

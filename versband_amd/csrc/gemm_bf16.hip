@@ -130,6 +130,24 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
             bf16x2 lv; lv[0] = f2bf(o0 - bf2f(h0)); lv[1] = f2bf(o1 - bf2f(h1));
             *reinterpret_cast<bf16x2*>(p.out + p.out_plane + idx) = lv;
         }
+    } else if constexpr (EPI == EPI_GEGLU) {
+        // T5DenseGatedActDense: gelu_new(wi_0 x) * (wi_1 x), NewGELUActivation = 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+        float o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float x = v[2 * i];
+            const float inner = 0.7978845608028654f * (x + 0.044715f * (x * x * x));
+            o[i] = (0.5f * x * (1.0f + tanhf(inner))) * v[2 * i + 1];
+        }
+        int64_t idx = (int64_t)m * p.ldc + g * p.c_noff_group + (n >> 1);
+        bf16_t h0 = f2bf(o[0]), h1 = f2bf(o[1]);
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 hv; hv[0] = h0; hv[1] = h1;
+        *reinterpret_cast<bf16x2*>(p.out + idx) = hv;
+        if (p.out_np == 2) {
+            bf16x2 lv; lv[0] = f2bf(o[0] - bf2f(h0)); lv[1] = f2bf(o[1] - bf2f(h1));
+            *reinterpret_cast<bf16x2*>(p.out + p.out_plane + idx) = lv;
+        }
     } else if constexpr (EPI == EPI_SCATTER_F32) {
         *reinterpret_cast<float4*>(p.out32 + (int64_t)tok * p.ldc32 + n) = make_float4(scale * v[0], scale * v[1], scale * v[2], scale * v[3]);
     } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
@@ -1111,6 +1129,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         VB_GEMM_CASE(EPI_GELU_PLANES)
         VB_GEMM_CASE(EPI_HEADS_T)
         VB_GEMM_CASE(EPI_F32_CT)
+        VB_GEMM_CASE(EPI_GEGLU)
         default: VB_FAIL(VB_E_INVALID, "gemm: bad epilogue %d", a.epi);
     }
 #undef VB_GEMM_CASE

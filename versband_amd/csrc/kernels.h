@@ -15,6 +15,7 @@ enum GemmEpi {
     EPI_SCATTER_ADD_PLANES = 6,  // planes[tok][n] = y32_in[tok][n] + row_scale[tok]*v
     EPI_GELU_PLANES = 7,     // planes = gelu_erf(v + bias)
     EPI_HEADS_T = 8,         // planes[((b*H+h)*hd+d)*Tpad + t] = v (+bias),  m = b*T+t, n = h*hd+d
+    EPI_GEGLU = 10,          // planes[m][n/2] = gelu_new(v[n]) * v[n+1]  (T5 gated-GELU FFN, rows of wi_0 / wi_1 interleaved)
     EPI_F32_CT = 9,          // out32[(b*N + n)*T + t] = v + bias  (channel-major [B][N][T] output of the FinalLayer), m = b*T+t
     EPI_COUNT = 9
 };
@@ -119,6 +120,9 @@ int launch_silu_sum_planes(const float* temb, const float* cemb, int rows, int D
 // LayerNorm (no affine, eps) + adaLN modulate -> split-bf16 planes (FinalLayer input, vocal2music_moe.py:287-291)
 int launch_layernorm_mod_planes(const float* h, const float* shift, const float* scale, int mod_ld, int rows, int D, int T, float eps,
                                 Planes out, hipStream_t st);
+// T5 (t5.hip)
+int launch_gather_rows(const int64_t* idx, const float* table, int rows, int D, int vocab, float* out, hipStream_t st);
+int launch_t5_attention(Planes qkv, const float* pos_bias, int pos_len, int B, int L, int heads, int dkv, Planes out, hipStream_t st);
 int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
                     int groups, int swish, float* out, hipStream_t st);
 int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st);

@@ -150,6 +150,40 @@ class DiTEngine:
         return (x, traj) if return_traj else x
 
 
+class T5Engine:
+    """transformers.T5EncoderModel(input_ids).last_hidden_state on the HIP library: token ids [B,L] ->
+    [B,L,d_model] fp32.  `sd` uses the HF state_dict keys; heads / eps / bucket parameters come from the HF config."""
+
+    def __init__(self, ctx: Context, sd: Dict[str, Tensor], num_heads: int = 16, d_kv: int = 64, eps: float = 1e-6, max_len: int = 128,
+                 num_buckets: int = 32, max_distance: int = 128):
+        ctx = Context(ctx.device)
+        self.ctx = ctx
+        top, layers = pack.pack_t5(sd, ctx.device, num_heads, max_len, num_buckets, max_distance)
+        self._keep = (top, layers)
+        d_ff = sd["encoder.block.0.layer.1.DenseReluDense.wi_0.weight"].shape[0]
+        self.cfg = L.T5Config(vocab=top["embed"].shape[0], d_model=top["embed"].shape[1], d_kv=d_kv, heads=num_heads, d_ff=d_ff,
+                              layers=len(layers), eps=eps)
+        w = L.T5Weights()
+        w.embed, w.pos_bias, w.pos_len = top["embed"].data_ptr(), top["pos_bias"].data_ptr(), max_len
+        w.final_ln, w.ones = top["final_ln"].data_ptr(), top["ones"].data_ptr()
+        for i, lw in enumerate(layers):
+            for f in L.T5_LAYER_FIELDS:
+                setattr(w.layers[i], f, lw[f].data_ptr())
+        L.check(ctx.lib.vb_t5_load(ctx.handle, C.byref(self.cfg), C.byref(w)), "vb_t5_load")
+        self._ws = None
+
+    def encode(self, ids: Tensor) -> Tensor:
+        dev = self.ctx.device
+        ids = ids.to(dev, torch.int64).contiguous()
+        B, Lc = ids.shape
+        n = self.ctx.lib.vb_t5_workspace_bytes(C.byref(self.cfg), B, Lc)
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, Lc, self.cfg.d_model, dtype=torch.float32, device=dev)
+        L.check(self.ctx.lib.vb_t5_encode(self.ctx.handle, L.ptr(ids), B, Lc, L.ptr(out), L.ptr(self._ws), L.stream_ptr()), "vb_t5_encode")
+        return out
+
+
 # ---------------------------------------------------------------------------
 # conv nets
 # ---------------------------------------------------------------------------

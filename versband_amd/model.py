@@ -170,10 +170,37 @@ class FrozenTextVocalEmbedder:
     def __init__(self, version="google/flan-t5-large", device="cuda", max_length=77, freeze=True, **kw):
         self.version, self.max_length, self.device = version, max_length, device
         self.width = 1024
+        self.t5_state: Dict[str, Tensor] = {}
+        self.t5_heads, self.t5_eps = 16, 1e-6           # flan-t5-large / t5-v1_1-large encoder
+        self._t5 = None
+        self._tokenizer = None
 
     def to(self, device):
         self.device = device
         return self
+
+    def load_state_dict(self, sd, strict=False):
+        """`transformer.*` weights of the reference's cond_stage_model (HF T5EncoderModel keys, prefix already stripped)."""
+        self.t5_state = {k: v for k, v in sd.items() if k.startswith("encoder.") or k == "shared.weight"}
+        self._t5 = None
+
+    def _t5_engine(self):
+        from .engine import Context, T5Engine
+        if self._t5 is None:
+            dev = self.device if str(self.device).startswith("cuda:") else "cuda:0"
+            self._t5 = T5Engine(Context(dev), self.t5_state, num_heads=self.t5_heads, eps=self.t5_eps)
+        return self._t5
+
+    def _tokenize(self, caps: List[str]) -> Optional[Tensor]:
+        """The tokenizer is upstream of the library; it is used when the checkpoint directory named by `version` is on disk."""
+        if self._tokenizer is None and os.path.isdir(self.version):
+            from transformers import T5Tokenizer
+            self._tokenizer = T5Tokenizer.from_pretrained(self.version)
+        if self._tokenizer is None:
+            return None
+        enc = self._tokenizer(text=caps, truncation=True, max_length=self.max_length, return_length=True, return_overflowing_tokens=False,
+                              padding="max_length", return_tensors="pt")
+        return enc["input_ids"]
 
     def _embed_text(self, caps: List[str]) -> Tensor:
         out = []
@@ -187,8 +214,14 @@ class FrozenTextVocalEmbedder:
 
     def __call__(self, c):
         cap = c["caption"]
-        if not torch.is_tensor(cap):
-            cap = self._embed_text(list(cap))
+        if torch.is_tensor(cap) and cap.dtype in (torch.int64, torch.int32) and cap.dim() == 2:
+            # token ids [B, L]: run the T5 encoder stack on the HIP library (modules.py:216-221 without the tokenizer)
+            if not self.t5_state:
+                raise RuntimeError("FrozenTextVocalEmbedder: token ids given but no cond_stage_model.transformer.* weights loaded")
+            cap = self._t5_engine().encode(cap)
+        elif not torch.is_tensor(cap):
+            ids = self._tokenize(list(cap)) if self.t5_state else None
+            cap = self._t5_engine().encode(ids) if ids is not None else self._embed_text(list(cap))
         return {"caption": cap.float(), "acoustic": c["acoustic"], "name": c.get("name")}
 
 
@@ -226,6 +259,10 @@ class CFM:
         vae = {k[len(fp):]: v for k, v in sd.items() if k.startswith(fp)}
         if vae:
             self.first_stage_model.load_state_dict(vae)
+        cp = "cond_stage_model.transformer."
+        t5 = {k[len(cp):]: v for k, v in sd.items() if k.startswith(cp)}
+        if t5 and hasattr(self.cond_stage_model, "load_state_dict"):
+            self.cond_stage_model.load_state_dict(t5)
         if "scale_factor" in sd:
             self.scale_factor = sd["scale_factor"].detach().float().cpu().reshape(())
         if strict:

@@ -155,3 +155,43 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
         b["wag"], b["bag"] = g(p + "feed_forward.acoustic_gating_network.weight"), g(p + "feed_forward.acoustic_gating_network.bias")
         blocks.append(b)
     return {"top": top, "blocks": blocks}
+
+
+def t5_position_bias(rel_emb: Tensor, L: int, num_buckets: int = 32, max_distance: int = 128) -> Tensor:
+    """[heads, L, L] relative-position bias of the T5 encoder (transformers T5Attention.compute_bias with bidirectional
+    buckets: half the buckets per sign, exact below num_buckets/4, logarithmic up to max_distance), built on the host."""
+    ctx = torch.arange(L, dtype=torch.long)[:, None]
+    mem = torch.arange(L, dtype=torch.long)[None, :]
+    rel = mem - ctx
+    nb = num_buckets // 2
+    bucket = (rel > 0).to(torch.long) * nb
+    rp = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    bucket = bucket + torch.where(rp < max_exact, rp, large)
+    return rel_emb.float()[bucket].permute(2, 0, 1).contiguous()
+
+
+def pack_t5(sd: Dict[str, Tensor], device, num_heads: int, max_len: int = 128, num_buckets: int = 32, max_distance: int = 128):
+    """transformers.T5EncoderModel state_dict -> tensors of vb_t5_weights (all GEMM operands as 2 bf16 planes)."""
+    g = lambda k: sd[k].to(device=device, dtype=torch.float32).contiguous()      # noqa: E731
+    n_layers = len({int(k.split(".")[2]) for k in sd if k.startswith("encoder.block.")})
+    top = {"embed": g("shared.weight") if "shared.weight" in sd else g("encoder.embed_tokens.weight"),
+           "pos_bias": t5_position_bias(sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"].cpu(), max_len,
+                                        num_buckets, max_distance).to(device),
+           "final_ln": g("encoder.final_layer_norm.weight")}
+    top["ones"] = torch.ones(top["embed"].shape[1], dtype=torch.float32, device=device)
+    layers = []
+    for i in range(n_layers):
+        p = f"encoder.block.{i}."
+        wi0, wi1 = g(p + "layer.1.DenseReluDense.wi_0.weight"), g(p + "layer.1.DenseReluDense.wi_1.weight")
+        layers.append({
+            "ln0": g(p + "layer.0.layer_norm.weight"),
+            "wqkv": to_planes(torch.cat([g(p + f"layer.0.SelfAttention.{n}.weight") for n in ("q", "k", "v")]), 2),
+            "wo": to_planes(g(p + "layer.0.SelfAttention.o.weight"), 2),
+            "ln1": g(p + "layer.1.layer_norm.weight"),
+            "wi": to_planes(torch.stack([wi0, wi1], dim=1).reshape(2 * wi0.shape[0], wi0.shape[1]).contiguous(), 2),
+            "wo_ff": to_planes(g(p + "layer.1.DenseReluDense.wo.weight"), 2),
+        })
+    return top, layers

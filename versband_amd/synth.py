@@ -69,6 +69,41 @@ class VAEConfig:
 
 
 @dataclass
+class T5Config:
+    """google/flan-t5-large encoder (cond_stage_config of configs/vocal2music.yaml:71-74; HF T5Config of that checkpoint)."""
+    vocab_size: int = 32128
+    d_model: int = 1024
+    d_kv: int = 64
+    num_heads: int = 16
+    d_ff: int = 2816
+    num_layers: int = 24
+    relative_attention_num_buckets: int = 32
+    relative_attention_max_distance: int = 128
+    layer_norm_epsilon: float = 1e-6
+
+
+def t5_encoder_shapes(cfg: "T5Config"):
+    """state_dict keys of transformers.T5EncoderModel (shared.weight is tied to encoder.embed_tokens.weight)."""
+    s: "OrderedDict[str, Tuple[Tuple[int, ...], tuple]]" = OrderedDict()
+    inner = cfg.num_heads * cfg.d_kv
+    s["shared.weight"] = ((cfg.vocab_size, cfg.d_model), ("u", 1.0))
+    for i in range(cfg.num_layers):
+        p = f"encoder.block.{i}."
+        for nm in ("q", "k", "v"):
+            s[p + f"layer.0.SelfAttention.{nm}.weight"] = ((inner, cfg.d_model), ("fan",))
+        s[p + "layer.0.SelfAttention.o.weight"] = ((cfg.d_model, inner), ("fan",))
+        if i == 0:
+            s[p + "layer.0.SelfAttention.relative_attention_bias.weight"] = ((cfg.relative_attention_num_buckets, cfg.num_heads), ("u", 1.0))
+        s[p + "layer.0.layer_norm.weight"] = ((cfg.d_model,), ("norm",))
+        s[p + "layer.1.DenseReluDense.wi_0.weight"] = ((cfg.d_ff, cfg.d_model), ("fan",))
+        s[p + "layer.1.DenseReluDense.wi_1.weight"] = ((cfg.d_ff, cfg.d_model), ("fan",))
+        s[p + "layer.1.DenseReluDense.wo.weight"] = ((cfg.d_model, cfg.d_ff), ("fan",))
+        s[p + "layer.1.layer_norm.weight"] = ((cfg.d_model,), ("norm",))
+    s["encoder.final_layer_norm.weight"] = ((cfg.d_model,), ("norm",))
+    return s
+
+
+@dataclass
 class HifiGanConfig:
     """<vocoder_ckpt>/config.yaml keys read by HifiGanGenerator.
     Defaults = the synthetic V1-like config of SURVEY §8(d)."""
