@@ -165,7 +165,9 @@ typedef struct { int channels; int tmul; int square; } vb_buf_desc;   /* square:
 /* VB_OP_RESPAIR: fused HiFi-GAN ResBlock1 pair (vocoder/hifigan/modules/hifigan.py ResBlock1.forward), Ci = Co = 32 or 64:
  * out = beta*out + alpha*(x + bias2 + conv2_k( lrelu( bias + conv1_{k,dil}( lrelu(x) ) ) )), w_x3 / w2_x3 split planes */
 /* VB_OP_GN_APPLY: out = GroupNorm affine of x from `stats` (+ swish when in_act == VB_ACT_GN_SWISH), same layout */
-enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3, VB_OP_RESPAIR = 4, VB_OP_GN_APPLY = 5 };
+/* VB_OP_AA_ACT: BigVGAN anti-aliased Snake / SnakeBeta (vocoder/bigvgan/alias_free_torch/act.py): out = down2(snake(up2(x))), Ci channels,
+ * gn_gamma = alpha (exp'ed when log-scale), gn_beta = 1 / (beta + 1e-9), w = the 12-tap Kaiser-sinc filter */
+enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3, VB_OP_RESPAIR = 4, VB_OP_GN_APPLY = 5, VB_OP_AA_ACT = 6 };
 enum { VB_ACT_NONE = 0, VB_ACT_LRELU = 1, VB_ACT_GN_SWISH = 2, VB_ACT_TANH = 3, VB_ACT_GN = 4 };
 #define VB_BUF_INPUT (-2)
 #define VB_BUF_OUTPUT (-3)

@@ -456,6 +456,33 @@ def gen_t5():
     print("t5", out.shape, out2.shape, float(out.abs().max()), float(out2.abs().max()))
 
 
+def gen_bigvgan(T=8):
+    """BigVGAN generator through the reference's own vocoder/bigvgan/models.py BigVGAN."""
+    import vocoder.bigvgan.models as M
+    import warnings
+    out = {}
+    for tag, cfg in (("amp1", synth.BigVGANConfig(upsample_initial_channel=128)),
+                     ("amp2", synth.BigVGANConfig(resblock="2", upsample_rates=(8, 8, 5), upsample_kernel_sizes=(16, 16, 11),
+                                                  upsample_initial_channel=64, resblock_kernel_sizes=(3, 5),
+                                                  resblock_dilation_sizes=((1, 3), (1, 3)), activation="snake", snake_logscale=False))):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = M.BigVGAN(types.SimpleNamespace(**cfg.as_hparams())).eval()
+        sd = synth.make_state_dict(synth.bigvgan_shapes(cfg), SEED + 7)
+        ref = {k for k in net.state_dict() if not k.endswith("filter")}
+        assert ref == set(sd), ref ^ set(sd)
+        for k in sd:
+            assert tuple(net.state_dict()[k].shape) == tuple(sd[k].shape), k
+        net.load_state_dict(sd, strict=False)
+        mel = torch.from_numpy(prng.uniform(prng.key_seed(SEED, "bv_mel"), 80 * T, -5.0, 1.5).reshape(1, 80, T))
+        with torch.no_grad():
+            wav = net(mel)
+        out[f"{tag}_mel"] = mel.numpy()
+        out[f"{tag}_wav"] = wav.numpy()
+        print("bigvgan", tag, wav.shape, float(wav.abs().max()), float(wav.std()))
+    np.savez_compressed(os.path.join(GOLD, "bigvgan.npz"), **out)
+
+
 def use_reference_paths():
     """Make `import ldm...` / `vocoder...` / `utils...` resolve to the REFERENCE: its packages have no __init__.py (namespace
     packages), so the build's same-named shim packages would win wherever they sit on sys.path.  versband_amd is already
@@ -480,6 +507,7 @@ def main():
     gen_hifigan()
     gen_sampler()
     gen_fullsize()
+    gen_bigvgan()
     gen_t5()
 
 

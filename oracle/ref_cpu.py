@@ -529,3 +529,76 @@ def normalize_loudness(wav, target_loudness: float):
     rms = np.sqrt(np.mean(wav ** 2))
     gain = target_loudness - 20 * np.log10(rms)
     return wav * 10 ** (gain / 20)
+
+
+# ---------------------------------------------------------------------------
+# BigVGAN generator: vocoder/bigvgan/models.py:133-213, activations.py, alias_free_torch/{act,resample,filter}.py
+# ---------------------------------------------------------------------------
+
+
+def kaiser_sinc_filter1d(cutoff: float, half_width: float, kernel_size: int) -> Tensor:
+    """alias_free_torch/filter.py:28-57 -> [kernel_size]."""
+    even = kernel_size % 2 == 0
+    half_size = kernel_size // 2
+    delta_f = 4 * half_width
+    A = 2.285 * (half_size - 1) * math.pi * delta_f + 7.95
+    beta = 0.1102 * (A - 8.7) if A > 50.0 else (0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0) if A >= 21.0 else 0.0)
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    time = (torch.arange(-half_size, half_size) + 0.5) if even else torch.arange(kernel_size) - half_size
+    f = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    return f / f.sum()
+
+
+def aa_activation(x: Tensor, alpha: Tensor, beta: Optional[Tensor], logscale: bool, ratio: int = 2, k: int = 12) -> Tensor:
+    """Activation1d (act.py): UpSample1d(2, 12) -> Snake / SnakeBeta -> DownSample1d(2, 12) (resample.py:10-49)."""
+    C = x.shape[1]
+    f = kaiser_sinc_filter1d(0.5 / ratio, 0.6 / ratio, k).view(1, 1, k).expand(C, -1, -1)
+    pad = k // ratio - 1
+    pad_left = pad * ratio + (k - ratio) // 2
+    pad_right = pad * ratio + (k - ratio + 1) // 2
+    y = F.pad(x, (pad, pad), mode="replicate")
+    y = ratio * F.conv_transpose1d(y, f, stride=ratio, groups=C)
+    y = y[..., pad_left:-pad_right]
+    a = alpha[None, :, None]
+    b = a if beta is None else beta[None, :, None]
+    if logscale:
+        a, b = torch.exp(a), torch.exp(b)
+    y = y + (1.0 / (b + 1e-9)) * torch.pow(torch.sin(y * a), 2)
+    y = F.pad(y, (k // 2 - 1, k // 2), mode="replicate")            # LowPassFilter1d: even kernel -> pad_left = k/2 - 1
+    return F.conv1d(y, f, stride=ratio, groups=C)
+
+
+def bigvgan_forward(sd: Dict[str, Tensor], hp: dict, mel: Tensor) -> Tensor:
+    """BigVGAN.forward models.py:181-205.  mel [B,num_mels,T] -> wav [B,1,T*hop]."""
+    nk = len(hp["resblock_kernel_sizes"])
+    logscale = bool(hp["snake_logscale"])
+
+    def act(name, x):
+        return aa_activation(x, sd[name + ".act.alpha"], sd.get(name + ".act.beta"), logscale)
+
+    x = F.conv1d(mel, _hg_w(sd, "conv_pre"), sd["conv_pre.bias"], padding=3)
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        x = F.conv_transpose1d(x, _hg_w(sd, f"ups.{i}.0"), sd[f"ups.{i}.0.bias"], stride=u, padding=(k - u) // 2)     # no activation before it
+        xs = None
+        for j, (rk, rd) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            n = i * nk + j
+            r = x
+            if hp["resblock"] == "1":                                   # AMPBlock1 :29-84
+                for m, d in enumerate(rd):
+                    xt = act(f"resblocks.{n}.activations.{2 * m}", r)
+                    xt = F.conv1d(xt, _hg_w(sd, f"resblocks.{n}.convs1.{m}"), sd[f"resblocks.{n}.convs1.{m}.bias"], dilation=d,
+                                  padding=int((rk * d - d) / 2))
+                    xt = act(f"resblocks.{n}.activations.{2 * m + 1}", xt)
+                    xt = F.conv1d(xt, _hg_w(sd, f"resblocks.{n}.convs2.{m}"), sd[f"resblocks.{n}.convs2.{m}.bias"], padding=int((rk - 1) / 2))
+                    r = xt + r
+            else:                                                       # AMPBlock2 :87-130
+                for m, d in enumerate(rd):
+                    xt = act(f"resblocks.{n}.activations.{m}", r)
+                    xt = F.conv1d(xt, _hg_w(sd, f"resblocks.{n}.convs.{m}"), sd[f"resblocks.{n}.convs.{m}.bias"], dilation=d,
+                                  padding=int((rk * d - d) / 2))
+                    r = xt + r
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = act("activation_post", x)
+    x = F.conv1d(x, _hg_w(sd, "conv_post"), sd["conv_post.bias"], padding=3)
+    return torch.tanh(x)

@@ -121,3 +121,21 @@ def test_cli_synthetic_end_to_end(tmp_path):
     rms_db = 20 * np.log10(np.sqrt(np.mean(pcm ** 2)))
     assert abs(rms_db + 23.0) < 0.5                      # normalize_loudness(-23 dB RMS), scripts/test_final.py:342-347
     assert (out / "clap.csv").exists()
+
+
+@pytest.mark.gpu
+def test_bigvgan_reference_api(tmp_path):
+    """VocoderBigVGAN(ckpt_dir)(mel) through the reference-named class and module path (best_netG.pt + args.yml on disk)."""
+    import yaml
+    from oracle import ref_cpu
+    from vocoder.bigvgan.models import VocoderBigVGAN
+    cfg = synth.BigVGANConfig(upsample_initial_channel=64)
+    sd = synth.make_state_dict(synth.bigvgan_shapes(cfg), 77)
+    torch.save({"generator": sd}, tmp_path / "best_netG.pt")
+    (tmp_path / "args.yml").write_text(yaml.safe_dump(cfg.as_hparams()))
+    voc = VocoderBigVGAN(str(tmp_path), device="cuda:0")
+    mel = synth.prng.uniform(3, 80 * 21, -5.0, 1.5).reshape(80, 21).astype(np.float32)
+    wav = voc(mel)
+    ref = ref_cpu.bigvgan_forward(sd, cfg.as_hparams(), torch.from_numpy(mel)[None]).view(-1).numpy()
+    assert wav.shape == ref.shape == (21 * 320,)
+    assert np.linalg.norm(wav - ref) / np.linalg.norm(ref) < 3e-4

@@ -337,6 +337,28 @@ def test_t5_encoder_vs_transformers_golden_and_oracle(ctx):
     check_digest(out24, g, "out24_", 3e-4)
 
 
+@pytest.mark.parametrize("tag", ["amp1", "amp2"])
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-5), ("split", 3e-4)])
+def test_bigvgan_vs_golden_and_oracle(ctx, tag, prec, tol):
+    """BigVGAN generator (anti-aliased Snake / SnakeBeta kernel + the shared conv kernels) against the reference's
+    own outputs and, on a ragged length, against the oracle."""
+    from tests.test_oracle_golden import _BV_CFGS
+    from versband_amd.engine import build_bigvgan
+    g = np.load(os.path.join(GOLD, "bigvgan.npz"))
+    cfg = synth.BigVGANConfig(**_BV_CFGS[tag])
+    sd = synth.make_state_dict(synth.bigvgan_shapes(cfg), SEED + 7)
+    net = build_bigvgan(ctx, sd, cfg.as_hparams(), precision=prec)
+    wav = net.run(torch.from_numpy(g[tag + "_mel"]))
+    torch.cuda.synchronize()
+    assert rel_l2(wav, g[tag + "_wav"]) < tol, describe("bigvgan vs reference", wav, g[tag + "_wav"])
+    mel = torch.from_numpy(synth.prng.uniform(31, 2 * 80 * 37, -5.0, 1.5).reshape(2, 80, 37))
+    ref = ref_cpu.bigvgan_forward(sd, cfg.as_hparams(), mel)
+    wav = net.run(mel)
+    torch.cuda.synchronize()
+    assert wav.shape == ref.shape
+    assert rel_l2(wav, ref) < tol, describe("bigvgan T=37 vs oracle", wav, ref)
+
+
 def test_full_size_properties(ctx, engines):
     """BASELINE geometry (T=752, L=80): size-independent checks - finite outputs, CFG with scale 1 equals the
     conditional-only path, padding frames beyond T never leak (Tpad masking), full-length VAE/vocoder shapes."""

@@ -143,3 +143,18 @@ def test_t5_encoder_matches_transformers(golden_dir):
     check_digest(out, g, "out_", 5e-6)
     sd24 = synth.make_state_dict(synth.t5_encoder_shapes(synth.T5Config(vocab_size=2048)), SEED + 5)
     check_digest(ref_cpu.t5_encode(sd24, torch.from_numpy(g["ids24"])), g, "out24_", 2e-5)
+
+
+_BV_CFGS = {"amp1": dict(upsample_initial_channel=128),
+            "amp2": dict(resblock="2", upsample_rates=(8, 8, 5), upsample_kernel_sizes=(16, 16, 11), upsample_initial_channel=64,
+                         resblock_kernel_sizes=(3, 5), resblock_dilation_sizes=((1, 3), (1, 3)), activation="snake", snake_logscale=False)}
+
+
+@pytest.mark.parametrize("tag", ["amp1", "amp2"])
+def test_bigvgan_matches_reference(golden_dir, tag):
+    """BigVGAN (AMPBlock1 + SnakeBeta log-scale / AMPBlock2 + Snake) against the reference's own generator."""
+    g = _load(golden_dir, "bigvgan.npz")
+    cfg = synth.BigVGANConfig(**_BV_CFGS[tag])
+    sd = synth.make_state_dict(synth.bigvgan_shapes(cfg), SEED + 7)
+    wav = ref_cpu.bigvgan_forward(sd, cfg.as_hparams(), torch.from_numpy(g[tag + "_mel"]))
+    assert _rel(wav, g[tag + "_wav"]) < 1e-5

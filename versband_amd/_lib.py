@@ -73,7 +73,7 @@ class NetOp(C.Structure):
                 + [("w_x3", c_void_p), ("ci_pad", c_int), ("w2_x3", c_void_p), ("bias2", c_void_p), ("in_stride", c_int), ("in_phase", c_int)])
 
 
-OP_CONV, OP_GN_STATS, OP_SOFTMAX_T, OP_SPLIT_PLANES, OP_RESPAIR, OP_GN_APPLY = 0, 1, 2, 3, 4, 5
+OP_CONV, OP_GN_STATS, OP_SOFTMAX_T, OP_SPLIT_PLANES, OP_RESPAIR, OP_GN_APPLY, OP_AA_ACT = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_LRELU, ACT_GN_SWISH, ACT_TANH, ACT_GN = 0, 1, 2, 3, 4
 BUF_INPUT, BUF_OUTPUT = -2, -3
 NET_VAE, NET_VOCODER, NET_VAE_ENCODER = 0, 1, 2

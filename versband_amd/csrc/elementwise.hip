@@ -870,6 +870,59 @@ int launch_layernorm_mod_planes(const float* h, const float* shift, const float*
     return VB_OK;
 }
 
+// BigVGAN anti-aliased periodic activation (alias_free_torch Activation1d, ratio 2, 12-tap Kaiser-sinc filter f):
+//   up[v]  = 2 * sum_i xp[i] f[v + 15 - 2 i]          xp = x replicate-padded by 5          (UpSample1d, resample.py:10-32)
+//   s[v]   = up[v] + inv_beta * sin^2(alpha * up[v])                                         (Snake / SnakeBeta, activations.py)
+//   out[t] = sum_k f[k] s[clamp(2 t + k - 5, 0, 2T-1)]                                       (DownSample1d / LowPassFilter1d)
+// One workgroup = 256 outputs of one (batch, channel) row: the 523 intermediate samples are computed once into LDS.
+#define AA_TT 256
+__global__ void __launch_bounds__(256) aa_act_kernel(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ inv_beta,
+                                                    const float* __restrict__ filt, int C, int T, float* out) {
+    __shared__ float xs[AA_TT + 16];
+    __shared__ float ss[2 * AA_TT + 16];
+    __shared__ float f[12];
+    const int row = blockIdx.y, c = row % C;
+    const int t0 = blockIdx.x * AA_TT;
+    const float* xr = x + (int64_t)row * T;
+    const int tid = threadIdx.x;
+    if (tid < 12) f[tid] = filt[tid];
+    for (int j = tid; j < AA_TT + 16; j += 256) {
+        int pos = t0 - 6 + j;
+        pos = pos < 0 ? 0 : (pos > T - 1 ? T - 1 : pos);
+        xs[j] = xr[pos];
+    }
+    __syncthreads();
+    const float a = alpha[c], ib = inv_beta[c];
+    for (int q = tid; q < 2 * AA_TT + 11; q += 256) {
+        int v = 2 * t0 - 5 + q;
+        v = v < 0 ? 0 : (v > 2 * T - 1 ? 2 * T - 1 : v);
+        const int i_lo = (v + 5) >> 1;                      // ceil((v + 4) / 2)
+        float up = 0.f;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const int i = i_lo + m;
+            const int tap = v + 15 - 2 * i;                 // 11 - (v+5)%2 ... >= 0 by construction for m < 6
+            if (tap >= 0 && tap < 12) up += xs[i - t0 + 1] * f[tap];
+        }
+        up *= 2.f;
+        const float sn = sinf(up * a);
+        ss[q] = up + ib * (sn * sn);
+    }
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t < T) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc += f[k] * ss[2 * tid + k];
+        out[(int64_t)row * T + t] = acc;
+    }
+}
+int launch_aa_act(const float* x, const float* alpha, const float* inv_beta, const float* filt, int B, int C, int T, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(aa_act_kernel, dim3(cdiv(T, AA_TT), B * C), dim3(256), 0, st, x, alpha, inv_beta, filt, C, T, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // A operand of the adaLN tabulation GEMM: row (step, sample) = silu(temb[step] + cemb[sample]) as split-bf16 planes
 __global__ void __launch_bounds__(256) silu_sum_planes_kernel(const float* __restrict__ temb, const float* __restrict__ cemb, int rows,
                                                              int D, int nsample, bf16_t* out, int64_t plane) {

@@ -533,6 +533,8 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
             float* stp = ptr(o.stats);
             VB_TRY(launch_gn_apply(ptr(o.x), stp, stp + (size_t)B * o.gn_groups, o.gn_gamma, o.gn_beta, B, o.Ci, tlen(o.x), o.gn_groups,
                                    o.in_act == ACT_GN_SWISH ? 1 : 0, ptr(o.out), st));
+        } else if (o.kind == VB_OP_AA_ACT) {
+            VB_TRY(launch_aa_act(ptr(o.x), o.gn_gamma, o.gn_beta, o.w, B, o.Ci, tlen(o.x), ptr(o.out), st));
         } else if (o.kind == VB_OP_RESPAIR) {
             RespairArgs r;
             r.x = ptr(o.x); r.out = ptr(o.out); r.B = B; r.C = o.Ci; r.T = tlen(o.x); r.k = o.ksize; r.dil = o.dil;

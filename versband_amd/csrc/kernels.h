@@ -123,6 +123,7 @@ int launch_layernorm_mod_planes(const float* h, const float* shift, const float*
 // T5 (t5.hip)
 int launch_gather_rows(const int64_t* idx, const float* table, int rows, int D, int vocab, float* out, hipStream_t st);
 int launch_t5_attention(Planes qkv, const float* pos_bias, int pos_len, int B, int L, int heads, int dkv, Planes out, hipStream_t st);
+int launch_aa_act(const float* x, const float* alpha, const float* inv_beta, const float* filt, int B, int C, int T, float* out, hipStream_t st);
 int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
                     int groups, int swish, float* out, hipStream_t st);
 int launch_split_rows(const float* x, int64_t rows, int cols, int cpad, bf16_t* out, int64_t plane, hipStream_t st);

@@ -240,6 +240,17 @@ class NetBuilder:
                                 Ci=ch, Co=ch, ksize=k, dil=dil, in_slope=slope, alpha=alpha, beta=beta, w_x3=p1.data_ptr(),
                                 w2_x3=p2.data_ptr(), ci_pad=ch))
 
+    def aa_act(self, x: int, out: int, ch: int, alpha: Tensor, beta: Optional[Tensor], logscale: bool):
+        """BigVGAN Activation1d(Snake / SnakeBeta): out = down2(act(up2(x))) (alias_free_torch/act.py)."""
+        if getattr(self, "_aa_filter", None) is None:
+            self._aa_filter = pack.kaiser_sinc_filter1d(0.25, 0.3, 12)
+        a = alpha.float()
+        b = a if beta is None else beta.float()
+        if logscale:
+            a, b = torch.exp(a), torch.exp(b)
+        self.ops.append(L.NetOp(kind=L.OP_AA_ACT, x=x, out=out, res=-1, stats=-1, w_buf=-1, Ci=ch, gn_gamma=self._t(a),
+                                gn_beta=self._t(1.0 / (b + 1e-9)), w=self._t(self._aa_filter)))
+
     def softmax_t(self, x: int, out: int):
         self.ops.append(L.NetOp(kind=L.OP_SOFTMAX_T, x=x, out=out, res=-1, stats=-1, w_buf=-1))
 
@@ -527,4 +538,69 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
     wpost = wt("conv_post")
     nb.conv(x, L.BUF_OUTPUT, ch, wpost.shape[0], pack.pack_conv(wpost), sd["conv_post.bias"], k=7, pad=3, in_act=L.ACT_LRELU,
             in_slope=0.01, out_act=L.ACT_TANH)
+    return ConvNet(ctx, L.NET_VOCODER, nb, wpre.shape[1], wpost.shape[0], tm)
+
+
+def build_bigvgan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str = "split") -> ConvNet:
+    """BigVGAN.forward (vocoder/bigvgan/models.py:181-205) as an op list: conv_pre, per stage ConvTranspose (no activation in
+    front of it) + the mean of the AMP blocks (anti-aliased Snake/SnakeBeta -> conv -> ... + x), anti-aliased activation,
+    conv_post, tanh.  Driven by the args.yml keys; weights are weight-norm pairs like the HiFi-GAN's."""
+    nb = NetBuilder(ctx.device, precision)
+
+    def wt(name):
+        if name + ".weight" in sd:
+            return sd[name + ".weight"].float()
+        return pack.fold_weight_norm(sd[name + ".weight_g"].float(), sd[name + ".weight_v"].float())
+
+    logscale = bool(hp["snake_logscale"])
+
+    def act(name, x, ch, tm):
+        out = nb.buf(ch, tm)
+        nb.aa_act(x, out, ch, sd[name + ".act.alpha"], sd.get(name + ".act.beta"), logscale)
+        return out
+
+    nk = len(hp["resblock_kernel_sizes"])
+    c0 = hp["upsample_initial_channel"]
+    wpre = wt("conv_pre")
+    x = nb.buf(c0, 1)
+    nb.conv(L.BUF_INPUT, x, wpre.shape[1], c0, pack.pack_conv(wpre), sd["conv_pre.bias"], k=7, pad=3)
+    tm, ch = 1, c0
+    for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+        cin, ch = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        tm *= u
+        xu = nb.buf(ch, tm)
+        nb.conv(x, xu, cin, ch, pack.pack_conv_transpose(wt(f"ups.{i}.0"), u), sd[f"ups.{i}.0.bias"], tr_stride=u, tr_pad=(k - u) // 2, tr_k=k)
+        nb.release(x)
+        xs = nb.buf(ch, tm)
+        for j, (rk, rd) in enumerate(zip(hp["resblock_kernel_sizes"], hp["resblock_dilation_sizes"])):
+            n = i * nk + j
+            r = xu
+            for m, d in enumerate(rd):
+                last = m == len(rd) - 1
+                dst = xs if last else nb.buf(ch, tm)
+                al, be = (1.0 / nk, 0.0 if j == 0 else 1.0) if last else (1.0, 0.0)
+                if hp["resblock"] == "1":
+                    a1 = act(f"resblocks.{n}.activations.{2 * m}", r, ch, tm)
+                    t1 = nb.buf(ch, tm)
+                    nb.conv(a1, t1, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs1.{m}")), sd[f"resblocks.{n}.convs1.{m}.bias"], k=rk,
+                            dil=d, pad=(rk * d - d) // 2)
+                    nb.release(a1)
+                    a2 = act(f"resblocks.{n}.activations.{2 * m + 1}", t1, ch, tm)
+                    nb.release(t1)
+                    nb.conv(a2, dst, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs2.{m}")), sd[f"resblocks.{n}.convs2.{m}.bias"], k=rk,
+                            pad=(rk - 1) // 2, res=r, alpha=al, beta=be)
+                    nb.release(a2)
+                else:
+                    a1 = act(f"resblocks.{n}.activations.{m}", r, ch, tm)
+                    nb.conv(a1, dst, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs.{m}")), sd[f"resblocks.{n}.convs.{m}.bias"], k=rk,
+                            dil=d, pad=(rk * d - d) // 2, res=r, alpha=al, beta=be)
+                    nb.release(a1)
+                if r != xu:
+                    nb.release(r)
+                r = dst
+        nb.release(xu)
+        x = xs
+    ap = act("activation_post", x, ch, tm)
+    wpost = wt("conv_post")
+    nb.conv(ap, L.BUF_OUTPUT, ch, wpost.shape[0], pack.pack_conv(wpost), sd["conv_post.bias"], k=7, pad=3, out_act=L.ACT_TANH)
     return ConvNet(ctx, L.NET_VOCODER, nb, wpre.shape[1], wpost.shape[0], tm)

@@ -506,6 +506,36 @@ class HifiGAN:
         return self.net().run(c.contiguous()).view(-1).cpu().numpy()
 
 
+class VocoderBigVGAN:
+    """vocoder/bigvgan/models.py:393-414: <ckpt_vocoder>/best_netG.pt ['generator'] + <ckpt_vocoder>/args.yml -> BigVGAN generator
+    on the HIP library (engine.build_bigvgan)."""
+
+    def __init__(self, ckpt_vocoder, device="cuda"):
+        import yaml
+        sd = torch.load(os.path.join(ckpt_vocoder, "best_netG.pt"), map_location="cpu")
+        self.state = {k: v for k, v in sd["generator"].items() if not k.endswith("filter")}     # the filters are recomputed
+        with open(os.path.join(ckpt_vocoder, "args.yml")) as f:
+            self.h = dict(yaml.safe_load(f))
+        self.device = torch.device(device if str(device) != "cuda" else "cuda:0")
+        self._net = None
+
+    def net(self):
+        from .engine import Context, build_bigvgan
+        if self._net is None:
+            self._net = build_bigvgan(Context(self.device), self.state, self.h)
+        return self._net
+
+    def vocode(self, spec):
+        """spec [80,T] numpy or [B,80,T] tensor -> squeezed float32 numpy waveform (models.py:406-411)."""
+        if isinstance(spec, np.ndarray):
+            spec = torch.from_numpy(spec).unsqueeze(0)
+        spec = spec.to(dtype=torch.float32)
+        return self.net().run(spec).squeeze().cpu().numpy()
+
+    def __call__(self, wav):
+        return self.vocode(wav)
+
+
 def normalize_loudness(wav, target_loudness):
     """scripts/test_final.py:342-347."""
     rms = np.sqrt(np.mean(wav ** 2))

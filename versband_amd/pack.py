@@ -195,3 +195,14 @@ def pack_t5(sd: Dict[str, Tensor], device, num_heads: int, max_len: int = 128, n
             "wo_ff": to_planes(g(p + "layer.1.DenseReluDense.wo.weight"), 2),
         })
     return top, layers
+
+
+def kaiser_sinc_filter1d(cutoff: float, half_width: float, kernel_size: int) -> Tensor:
+    """vocoder/bigvgan/alias_free_torch/filter.py:28-57: the Kaiser-windowed sinc low-pass of BigVGAN's anti-aliased activations."""
+    half_size = kernel_size // 2
+    A = 2.285 * (half_size - 1) * math.pi * (4 * half_width) + 7.95
+    beta = 0.1102 * (A - 8.7) if A > 50.0 else (0.5842 * (A - 21) ** 0.4 + 0.07886 * (A - 21.0) if A >= 21.0 else 0.0)
+    window = torch.kaiser_window(kernel_size, beta=beta, periodic=False)
+    time = (torch.arange(-half_size, half_size) + 0.5) if kernel_size % 2 == 0 else torch.arange(kernel_size) - half_size
+    f = 2 * cutoff * window * torch.sinc(2 * cutoff * time)
+    return (f / f.sum()).float()

@@ -325,6 +325,69 @@ def hifigan_shapes(cfg: HifiGanConfig):
     return s
 
 
+@dataclass
+class BigVGANConfig:
+    """args.yml keys read by vocoder/bigvgan/models.py BigVGAN (synthetic config: same geometry as the HiFi-GAN one, hop 320)."""
+    resblock: str = "1"
+    upsample_rates: Tuple[int, ...] = (8, 5, 4, 2)
+    upsample_kernel_sizes: Tuple[int, ...] = (16, 15, 8, 4)
+    upsample_initial_channel: int = 512
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    num_mels: int = 80
+    activation: str = "snakebeta"
+    snake_logscale: bool = True
+
+    def as_hparams(self) -> dict:
+        return {"resblock": self.resblock, "upsample_rates": list(self.upsample_rates), "upsample_kernel_sizes": list(self.upsample_kernel_sizes),
+                "upsample_initial_channel": self.upsample_initial_channel, "resblock_kernel_sizes": list(self.resblock_kernel_sizes),
+                "resblock_dilation_sizes": [list(d) for d in self.resblock_dilation_sizes], "num_mels": self.num_mels,
+                "activation": self.activation, "snake_logscale": self.snake_logscale}
+
+
+def bigvgan_shapes(cfg: BigVGANConfig):
+    """Trainable keys of BigVGAN.state_dict() (vocoder/bigvgan/models.py:133-170); the anti-aliasing filters are buffers the
+    module computes itself and are not listed."""
+    s: "OrderedDict[str, Tuple[Tuple[int, ...], tuple]]" = OrderedDict()
+
+    def wn(name, shape, fan_in, transposed=False):
+        s[name + ".bias"] = ((shape[1] if transposed else shape[0],), ("u", 0.02))
+        s[name + ".weight_g"] = ((shape[0], 1, 1), ("pos",))
+        s[name + ".weight_v"] = (shape, ("u", 1.0 / fan_in ** 0.5))
+
+    def act(name, ch):
+        s[name + ".act.alpha"] = ((ch,), ("u", 0.7))                 # log-scale (or linear around 1 +- handled by the kind below)
+        if cfg.activation == "snakebeta":
+            s[name + ".act.beta"] = ((ch,), ("u", 0.7))
+
+    c0 = cfg.upsample_initial_channel
+    wn("conv_pre", (c0, cfg.num_mels, 7), cfg.num_mels * 7)
+    ch = c0
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        cin, cout = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        wn(f"ups.{i}.0", (cin, cout, k), cin * k / u, transposed=True)
+        ch = cout
+        for j, (rk, rd) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            n = i * nk + j
+            if cfg.resblock == "1":
+                for m in range(len(rd)):
+                    wn(f"resblocks.{n}.convs1.{m}", (ch, ch, rk), ch * rk)
+                for m in range(len(rd)):
+                    wn(f"resblocks.{n}.convs2.{m}", (ch, ch, rk), ch * rk)
+                for m in range(2 * len(rd)):
+                    act(f"resblocks.{n}.activations.{m}", ch)
+            else:
+                for m in range(len(rd)):
+                    wn(f"resblocks.{n}.convs.{m}", (ch, ch, rk), ch * rk)
+                for m in range(len(rd)):
+                    act(f"resblocks.{n}.activations.{m}", ch)
+    act("activation_post", ch)
+    wn("conv_post", (1, ch, 7), ch * 7)
+    s["conv_post.weight_g"] = ((1, 1, 1), ("pos", 0.07))      # keeps the synthetic generator's tanh input O(0.5): unsaturated output
+    return s
+
+
 def make_state_dict(shapes, seed: int, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for name, (shape, kind) in shapes.items():
@@ -335,7 +398,7 @@ def make_state_dict(shapes, seed: int, prefix: str = "") -> "OrderedDict[str, to
         elif kind[0] == "norm":
             v = prng.uniform(ks, n, 0.8, 1.2)
         elif kind[0] == "pos":
-            v = prng.uniform(ks, n, 0.5, 1.5)
+            v = prng.uniform(ks, n, 0.5, 1.5) * (kind[1] if len(kind) > 1 else 1.0)
         elif kind[0] == "fan":
             fan_in = int(np.prod(shape[1:]))
             b = 1.0 / fan_in ** 0.5
