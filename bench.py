@@ -190,12 +190,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VB_BENCH_ONE_DEVICE"):          # functional test of the N > 1 code path on a 1-GPU box (gloo, all ranks on cuda:0)
+        local = 0
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if os.environ.get("VB_BENCH_ONE_DEVICE"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     from tests.helpers import clip_batch
     from versband_amd import _lib as L
     from versband_amd import model as vm
