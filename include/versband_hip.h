@@ -158,7 +158,8 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
  * AutoencoderKL.decode (ldm/models/autoencoder1d.py:55-58, Decoder1D :480-512) and
  * HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) both run as a flat op
  * list over fp32 [B][C][T] buffers; the list is built from the model config by the host side. */
-typedef struct { int channels; int tmul; int square; } vb_buf_desc;   /* square: 1 = [T*tmul]^2 floats, 2 = channels x roundup(T*tmul, 32) */
+typedef struct { int channels; int tmul; int square; } vb_buf_desc;   /* square: 1 = [T*tmul]^2 floats, 2 = channels x roundup(T*tmul, 32),
+                                                                         3 = channels x (T*tmul + 448) (transposed planes with halo) */
 /* VB_OP_SPLIT_PLANES: x (f32 [B][rows][cols], rows = Co, cols = Ci, -1 = the buffer's time length) -> out = split-bf16
  * planes [2][B][rows][roundup(cols, 32)]; a later VB_OP_CONV with w_buf = that buffer and ci_pad = -1 uses them as
  * per-batch weights on the bf16x3 kernel (the VAE decoder's single-head attention) */
@@ -167,7 +168,10 @@ typedef struct { int channels; int tmul; int square; } vb_buf_desc;   /* square:
 /* VB_OP_GN_APPLY: out = GroupNorm affine of x from `stats` (+ swish when in_act == VB_ACT_GN_SWISH), same layout */
 /* VB_OP_AA_ACT: BigVGAN anti-aliased Snake / SnakeBeta (vocoder/bigvgan/alias_free_torch/act.py): out = down2(snake(up2(x))), Ci channels,
  * gn_gamma = alpha (exp'ed when log-scale), gn_beta = 1 / (beta + 1e-9), w = the 12-tap Kaiser-sinc filter */
-enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3, VB_OP_RESPAIR = 4, VB_OP_GN_APPLY = 5, VB_OP_AA_ACT = 6 };
+/* VB_OP_XT_PLANES: x (f32 [B][Ci][T]) -> out = pre-activated (in_act with `stats` / gn_gamma / gn_beta / in_slope), nearest-x2
+ * upsampled (upsample2), split-bf16 TRANSPOSED planes with zero halo rows; a VB_OP_CONV with x_planes = 1 reads them by DMA */
+enum { VB_OP_CONV = 0, VB_OP_GN_STATS = 1, VB_OP_SOFTMAX_T = 2, VB_OP_SPLIT_PLANES = 3, VB_OP_RESPAIR = 4, VB_OP_GN_APPLY = 5, VB_OP_AA_ACT = 6,
+       VB_OP_XT_PLANES = 7 };
 enum { VB_ACT_NONE = 0, VB_ACT_LRELU = 1, VB_ACT_GN_SWISH = 2, VB_ACT_TANH = 3, VB_ACT_GN = 4 };
 #define VB_BUF_INPUT (-2)
 #define VB_BUF_OUTPUT (-3)
@@ -180,6 +184,7 @@ typedef struct {
     const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
     const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution */
     int in_stride, in_phase;                 /* VB_OP_CONV: the convolution reads x[i*in_stride + in_phase] (0/1 = plain) */
+    int x_planes;                            /* VB_OP_CONV: x is a VB_OP_XT_PLANES buffer (upsample2 then describes how it was made) */
 } vb_net_op;
 
 enum { VB_NET_VAE = 0, VB_NET_VOCODER = 1, VB_NET_VAE_ENCODER = 2 };

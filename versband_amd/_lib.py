@@ -70,10 +70,10 @@ class NetOp(C.Structure):
                 + [(n, c_int) for n in ("Ci", "Co", "ksize", "dil", "pad", "upsample2", "in_act", "out_act", "out_transposed",
                                         "tr_stride", "tr_pad", "tr_k", "gn_groups")]
                 + [(n, c_float) for n in ("in_slope", "out_slope", "alpha", "beta", "acc_scale")]
-                + [("w_x3", c_void_p), ("ci_pad", c_int), ("w2_x3", c_void_p), ("bias2", c_void_p), ("in_stride", c_int), ("in_phase", c_int)])
+                + [("w_x3", c_void_p), ("ci_pad", c_int), ("w2_x3", c_void_p), ("bias2", c_void_p), ("in_stride", c_int), ("in_phase", c_int), ("x_planes", c_int)])
 
 
-OP_CONV, OP_GN_STATS, OP_SOFTMAX_T, OP_SPLIT_PLANES, OP_RESPAIR, OP_GN_APPLY, OP_AA_ACT = 0, 1, 2, 3, 4, 5, 6
+OP_CONV, OP_GN_STATS, OP_SOFTMAX_T, OP_SPLIT_PLANES, OP_RESPAIR, OP_GN_APPLY, OP_AA_ACT, OP_XT_PLANES = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_LRELU, ACT_GN_SWISH, ACT_TANH, ACT_GN = 0, 1, 2, 3, 4
 BUF_INPUT, BUF_OUTPUT = -2, -3
 NET_VAE, NET_VOCODER, NET_VAE_ENCODER = 0, 1, 2

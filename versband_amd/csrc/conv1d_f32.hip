@@ -37,6 +37,7 @@ struct ConvDev {
     int phases, tr_pad;      // phases == 1: ordinary convolution
     const bf16_t* wp; int64_t wp_plane; int Ci_pad;   // split-bf16 weights [2 planes][phase][tap][Co][Ci_pad]
     int64_t wp_bstride;
+    const bf16_t* xt; int64_t xt_plane; int xt_Tp;     // pre-activated transposed split planes of the input (XT mode)
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -246,6 +247,8 @@ static void launch_cfg(const ConvDev& d, int n_count, int B, hipStream_t st) {
 #define CKP3 40      // bf16 elements per LDS row (32 + 8 pad)
 
 // ABL (tuning only): 1 = window staged once, 2 = weights staged once, 3 = no MFMA, 4 = no epilogue
+// ABL == 5 is not an ablation but the XT input mode: the window comes from pre-activated, transposed split planes (xt_planes_kernel)
+// by DMA (global_load_lds) - no register staging, no per-tile transform/split; LDS rows are 64 B, XOR-swizzled instead of padded.
 template <int WM, int WN, int TM, int TN, int ABL = 0>
 __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
     constexpr int CO_TILE = WM * TM * 32;
@@ -386,13 +389,33 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
     };
 
     const int nchunks = (p.Ci + CK3 - 1) / CK3;
-    xload(0);
+    // XT mode: DMA of one chunk's window = xw_used rows x 64 B per plane, in 1-KB pieces of 16 rows; lane -> (row, 16-B slot),
+    // the slot holds source chunk slot ^ ((row >> 2) & 3)
+    auto xt_issue = [&](int c0) {
+        typedef __attribute__((address_space(3))) void* lds_p;
+        typedef const __attribute__((address_space(1))) void* glb_p;
+        const int P = (xw_used + 15) >> 4;
+        for (int q = wave; q < 2 * P; q += 4) {
+            const int pl = q >= P, pr = q - pl * P;
+            const int row = pr * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const bf16_t* src = p.xt + pl * p.xt_plane + ((int64_t)xb * p.xt_Tp + (n0 + in_off + XT_HEAD + row)) * p.Ci + c0 + c * 8;
+            __builtin_amdgcn_global_load_lds((glb_p)src, (lds_p)(&xT[pl][pr * 16 * 32]), 16, 0, 0);
+        }
+    };
+    if constexpr (ABL != 5) xload(0);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = ch * CK3;
+        if constexpr (ABL == 5) {
+            xt_issue(c0);                       // every wave is past the previous chunk's last tap (barrier below)
+            wload(c0, 0); wstore(0);
+            __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0): the window landed
+        } else {
         if (ABL != 1 || ch == 0) xstore(c0);
         if (ABL != 2 || ch == 0) { wload(c0, 0); wstore(0); }
+        }
         __syncthreads();
-        if (ABL != 1 && ch + 1 < nchunks) xload(c0 + CK3);
+        if (ABL != 1 && ABL != 5 && ch + 1 < nchunks) xload(c0 + CK3);
         for (int j = 0; j < p.ntaps; ++j) {
             const int buf = (ABL == 2) ? 0 : (j & 1);
             if (ABL != 2 && j + 1 < p.ntaps) wload(c0, j + 1);
@@ -409,7 +432,8 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
                 }
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    const int o = ((wn * TN + jn) * 32 + l31 + xoff) * CKP3 + kofs;
+                    const int row = (wn * TN + jn) * 32 + l31 + xoff;
+                    const int o = (ABL == 5) ? row * 32 + (((kofs >> 3) ^ ((row >> 2) & 3)) << 3) : row * CKP3 + kofs;
                     bh[jn] = *reinterpret_cast<const bf16x8*>(&xT[0][o]);
                     bl[jn] = *reinterpret_cast<const bf16x8*>(&xT[1][o]);
                 }
@@ -453,6 +477,11 @@ static void launch_cfg_x3(const ConvDev& d, int n_count, int B, hipStream_t st) 
     else if (abl == 4) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 4>), grid, dim3(256), 0, st, d);
     else hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 0>), grid, dim3(256), 0, st, d);
 }
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg_xt(const ConvDev& d, int n_count, int B, hipStream_t st) {
+    dim3 grid(cdiv(n_count, WN * TN * 32), cdiv(d.Co, WM * TM * 32), B * d.phases);
+    hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 5>), grid, dim3(256), 0, st, d);
+}
 
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     ConvDev d;
@@ -466,6 +495,9 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     d.alpha = a.alpha; d.beta = a.beta; d.acc_scale = a.acc_scale; d.out_act = a.out_act; d.out_slope = a.out_slope;
     d.out_transposed = a.out_transposed; d.add = a.add; d.add_bstride = a.add_bstride; d.add_bmod = a.add_bmod;
     d.wp = a.wp; d.wp_plane = a.wp_plane; d.Ci_pad = a.Ci_pad; d.wp_bstride = a.wp_bstride;
+    d.xt = a.xt; d.xt_Tp = xt_rows(a.upsample2 ? 2 * a.T_in : a.T_in); d.xt_plane = (int64_t)a.B * d.xt_Tp * a.Ci;
+    if (a.xt && (a.Ci % CK3 || a.tr_stride > 1 || a.in_stride > 1 || !a.wp || a.x_bmod || a.pad > XT_HEAD))
+        VB_FAIL(VB_E_INVALID, "conv1d: XT input needs Ci %% 32 == 0, stride 1, split weights, pad <= %d", XT_HEAD);
     int n_count;
     if (a.tr_stride > 1) {
         d.phases = a.tr_stride; d.tr_pad = a.tr_pad; d.ntaps = (a.tr_k + a.tr_stride - 1) / a.tr_stride; d.dil = 1;
@@ -487,7 +519,11 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
         // B = 8 makes 288) runs as two rounds at 56 % - the 128co x 128t tile (71 KB, two per CU) halves the granule
         const int64_t blocks = (int64_t)cdiv(n_count, 256) * cdiv(a.Co, 128) * a.B * d.phases;
         const double eff = (double)blocks / (double)(cdiv(blocks, 256) * 256);
-        if (a.Co > 64 && (eff < 0.7 || cfgv == 3) && cfgv != 2) launch_cfg_x3<2, 2, 2, 1>(d, n_count, a.B, st);
+        if (a.xt) {
+            if (a.Co <= 64) VB_FAIL(VB_E_INVALID, "conv1d: XT input is built for Co > 64 (wide layers)");
+            if (eff < 0.7) launch_cfg_xt<2, 2, 2, 1>(d, n_count, a.B, st);
+            else launch_cfg_xt<2, 2, 2, 2>(d, n_count, a.B, st);
+        } else if (a.Co > 64 && (eff < 0.7 || cfgv == 3) && cfgv != 2) launch_cfg_x3<2, 2, 2, 1>(d, n_count, a.B, st);
         else if (a.Co > 64) launch_cfg_x3<2, 2, 2, 2>(d, n_count, a.B, st);
         else if (a.Co > 32 && cfgv == 1) launch_cfg_x3<2, 2, 1, 4>(d, n_count, a.B, st);
         else if (a.Co > 32) launch_cfg_x3<2, 2, 1, 2>(d, n_count, a.B, st);

@@ -870,6 +870,68 @@ int launch_layernorm_mod_planes(const float* h, const float* shift, const float*
     return VB_OK;
 }
 
+// Pre-pass for wide conv layers: x f32 [B][C][T] -> activated, split-bf16, TRANSPOSED planes [2][B][Tp][C] (C contiguous), with
+// XT_HEAD zero rows in front and zero rows behind (Tp = T_eff + XT_HEAD + XT_TAIL), so the conv kernel can DMA its input window
+// straight into LDS: the pointwise transform (GroupNorm affine, swish, LeakyReLU), the hi/lo split, the transpose and the zero
+// padding happen ONCE here instead of once per output-channel tile of the convolution (12 tiles on the 1536-channel layers).
+__global__ void __launch_bounds__(256) xt_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int groups, int act,
+                                                       float slope, int upsample2, int C, int T_in, int Tp, bf16_t* out, int64_t plane) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, r0 = blockIdx.x * 64;          // r = row of the padded image
+    const int T_eff = upsample2 ? 2 * T_in : T_in;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int cpg = groups > 0 ? C / groups : 1;
+    {
+        const int t = r0 + tx - XT_HEAD;
+        const bool tin = t >= 0 && t < T_eff;
+        const int ts = upsample2 ? (t >> 1) : t;
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc;
+            float v = 0.f;
+            if (tin && c < C) {
+                v = x[((int64_t)b * C + c) * T_in + ts];
+                if (act == ACT_GN || act == ACT_GN_SWISH) {
+                    const int grp = c / cpg;
+                    const float rs = rstd[b * groups + grp] * gamma[c];
+                    v = v * rs + (beta[c] - mean[b * groups + grp] * rs);
+                    if (act == ACT_GN_SWISH) v = v / (1.f + __expf(-v));
+                } else if (act == ACT_LRELU) {
+                    v = v > 0.f ? v : v * slope;
+                }
+            }
+            tile[tx][cc] = v;
+        }
+    }
+    __syncthreads();
+    const int tr = threadIdx.x >> 2, cg = (threadIdx.x & 3) * 16;
+    const int r = r0 + tr;
+    if (r < Tp && c0 + cg < C) {
+        bf16x8 hi[2], lo[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = tile[tr][cg + e];
+            const bf16_t h = f2bf(v);
+            hi[e >> 3][e & 7] = h;
+            lo[e >> 3][e & 7] = f2bf(v - bf2f(h));
+        }
+        bf16_t* dst = out + ((int64_t)b * Tp + r) * C + c0 + cg;
+        *reinterpret_cast<bf16x8*>(dst) = hi[0];
+        *reinterpret_cast<bf16x8*>(dst + 8) = hi[1];
+        *reinterpret_cast<bf16x8*>(dst + plane) = lo[0];
+        *reinterpret_cast<bf16x8*>(dst + plane + 8) = lo[1];
+    }
+}
+int launch_xt_planes(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups, int act,
+                     float slope, int upsample2, int B, int C, int T_in, bf16_t* out, hipStream_t st) {
+    if (C % 16) VB_FAIL(VB_E_INVALID, "xt_planes: C %% 16");
+    const int Tp = xt_rows(upsample2 ? 2 * T_in : T_in);
+    hipLaunchKernelGGL(xt_planes_kernel, dim3(cdiv(Tp, 64), cdiv(C, 64), B), dim3(256), 0, st, x, mean, rstd, gamma, beta, groups, act, slope,
+                       upsample2, C, T_in, Tp, out, (int64_t)B * Tp * C);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // BigVGAN anti-aliased periodic activation (alias_free_torch Activation1d, ratio 2, 12-tap Kaiser-sinc filter f):
 //   up[v]  = 2 * sum_i xp[i] f[v + 15 - 2 i]          xp = x replicate-padded by 5          (UpSample1d, resample.py:10-32)
 //   s[v]   = up[v] + inv_beta * sin^2(alpha * up[v])                                         (Snake / SnakeBeta, activations.py)

@@ -462,7 +462,8 @@ static size_t net_ws_bytes(const NetProgram& n, int B, int T, std::vector<size_t
     if (offs) offs->clear();
     for (const vb_buf_desc& d : n.bufs) {
         size_t tl = (size_t)T * d.tmul;
-        size_t el = d.square == 1 ? tl * tl : (d.square == 2 ? (size_t)d.channels * ((tl + 31) / 32 * 32) : (size_t)d.channels * tl);
+        size_t el = d.square == 1 ? tl * tl : (d.square == 2 ? (size_t)d.channels * ((tl + 31) / 32 * 32)
+                                  : (d.square == 3 ? (size_t)d.channels * (tl + XT_HEAD + XT_TAIL) : (size_t)d.channels * tl));
         if (offs) offs->push_back(off);
         off = align_up(off + el * B * sizeof(float));
     }
@@ -504,6 +505,11 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
         } else if (o.kind == VB_OP_CONV) {
             ConvArgs a;
             a.x = ptr(o.x); a.x_bstride = bstride(o.x); a.T_in = tlen(o.x);
+            if (o.x_planes) {
+                // input written by VB_OP_XT_PLANES: its buffer's time length is the (upsampled) length the planes were made for
+                a.xt = reinterpret_cast<const bf16_t*>(ptr(o.x));
+                a.T_in = o.upsample2 ? tlen(o.x) / 2 : tlen(o.x);
+            }
             a.Ci = o.Ci > 0 ? o.Ci : tlen(o.x);            // dynamic channel counts: the VAE attention contracts over T
             if (o.w_buf != -1) { a.w = ptr(o.w_buf); a.w_bstride = bstride(o.w_buf); } else { a.w = o.w; }
             a.bias = o.bias; a.Co = o.Co > 0 ? o.Co : tlen(o.out); a.ksize = o.ksize; a.dil = o.dil; a.pad = o.pad; a.upsample2 = o.upsample2;
@@ -533,6 +539,10 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
             float* stp = ptr(o.stats);
             VB_TRY(launch_gn_apply(ptr(o.x), stp, stp + (size_t)B * o.gn_groups, o.gn_gamma, o.gn_beta, B, o.Ci, tlen(o.x), o.gn_groups,
                                    o.in_act == ACT_GN_SWISH ? 1 : 0, ptr(o.out), st));
+        } else if (o.kind == VB_OP_XT_PLANES) {
+            const float* stp = o.stats >= 0 ? ptr(o.stats) : nullptr;
+            VB_TRY(launch_xt_planes(ptr(o.x), stp, stp ? stp + (size_t)B * o.gn_groups : nullptr, o.gn_gamma, o.gn_beta, o.gn_groups, o.in_act, o.in_slope,
+                                    o.upsample2, B, o.Ci, tlen(o.x), reinterpret_cast<bf16_t*>(ptr(o.out)), st));
         } else if (o.kind == VB_OP_AA_ACT) {
             VB_TRY(launch_aa_act(ptr(o.x), o.gn_gamma, o.gn_beta, o.w, B, o.Ci, tlen(o.x), ptr(o.out), st));
         } else if (o.kind == VB_OP_RESPAIR) {

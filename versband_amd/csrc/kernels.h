@@ -96,6 +96,9 @@ struct ConvArgs {
     // optional split-bf16 weights [2][phase][tap][Co][Ci_pad] (Ci_pad % 32 == 0): selects the bf16x3 MFMA kernel
     const bf16_t* wp = nullptr; int64_t wp_plane = 0; int Ci_pad = 0;
     int64_t wp_bstride = 0;          // per-batch split weights (bf16 elements inside a plane), VAE attention
+    // optional pre-activated transposed split planes of the input (xt_planes_kernel): [2][B][xt_rows(T_in)][Ci]; x / in_act /
+    // GroupNorm fields are then ignored and the window is DMA'd straight into LDS
+    const bf16_t* xt = nullptr;
 };
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
 // fused HiFi-GAN ResBlock1 pair (respair_x3.hip): out = beta*out + alpha*(x + b2 + conv2(lrelu(b1 + conv1_dil(lrelu(x)))))
@@ -123,6 +126,12 @@ int launch_layernorm_mod_planes(const float* h, const float* shift, const float*
 // T5 (t5.hip)
 int launch_gather_rows(const int64_t* idx, const float* table, int rows, int D, int vocab, float* out, hipStream_t st);
 int launch_t5_attention(Planes qkv, const float* pos_bias, int pos_len, int B, int L, int heads, int dkv, Planes out, hipStream_t st);
+// transposed split planes for the DMA-fed conv path (see xt_planes_kernel): rows of the padded image
+#define XT_HEAD 64
+#define XT_TAIL 384
+static inline int xt_rows(int T_eff) { return T_eff + XT_HEAD + XT_TAIL; }
+int launch_xt_planes(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups, int act,
+                     float slope, int upsample2, int B, int C, int T_in, bf16_t* out, hipStream_t st);
 int launch_aa_act(const float* x, const float* alpha, const float* inv_beta, const float* filt, int B, int C, int T, float* out, hipStream_t st);
 int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
                     int groups, int swish, float* out, hipStream_t st);

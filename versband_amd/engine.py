@@ -257,14 +257,16 @@ class NetBuilder:
     def conv(self, x: int, out: int, Ci: int, Co: int, w: Optional[Tensor] = None, bias: Optional[Tensor] = None, k: int = 1,
              dil: int = 1, pad: int = 0, res: int = -1, stats: int = -1, gamma=None, beta_gn=None, in_act=L.ACT_NONE,
              in_slope=0.0, out_act=L.ACT_NONE, out_slope=0.0, upsample2=0, out_transposed=0, w_buf=-1, alpha=1.0, beta=0.0,
-             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32, w_buf_planes=False, in_stride=1, in_phase=0):
+             acc_scale=1.0, tr_stride=1, tr_pad=0, tr_k=0, groups=32, w_buf_planes=False, in_stride=1, in_phase=0, x_is_planes=False):
         w_x3, ci_pad = None, (-1 if w_buf_planes else 0)
         tmp = -1
-        if (self.precision == "split" and in_act in (L.ACT_GN_SWISH, L.ACT_GN) and stats >= 0 and x >= 0 and Co >= self.GN_PREPASS_MIN_CO
-                and not upsample2):
-            # wide layer: apply the norm (+swish) once instead of once per 128-wide output-channel tile
-            tmp = self.gn_apply(x, Ci, stats, gamma, beta_gn, in_act, groups)
-            x, stats, gamma, beta_gn, in_act = tmp, -1, None, None, L.ACT_NONE
+        x_planes = int(bool(x_is_planes))
+        if (self.precision == "split" and not x_planes and w is not None and w_buf == -1 and x >= 0 and Co >= self.XT_MIN_CO and Ci % 32 == 0
+                and tr_stride == 1 and in_stride == 1 and pad <= 64 and (k - 1) * dil <= 64 and (k > 1 or in_act != L.ACT_NONE)):
+            # wide layer (>= 3 output-channel tiles): the input is activated, split and transposed ONCE (VB_OP_XT_PLANES) and every
+            # tile of the convolution DMAs its window from there, instead of each tile redoing norm / swish / split while staging
+            tmp = self.xt_planes(x, Ci, stats, gamma, beta_gn, in_act, in_slope, upsample2, groups)
+            x, stats, gamma, beta_gn, in_act, x_planes = tmp, -1, None, None, L.ACT_NONE, 1
         if self.precision == "split" and w is not None and w_buf == -1:
             planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
             self.keep.append(planes)
@@ -273,11 +275,19 @@ class NetBuilder:
                      gn_gamma=self._t(gamma), gn_beta=self._t(beta_gn), Ci=Ci, Co=Co, ksize=k, dil=dil, pad=pad,
                      upsample2=upsample2, in_act=in_act, out_act=out_act, out_transposed=out_transposed, tr_stride=tr_stride,
                      tr_pad=tr_pad, tr_k=tr_k, gn_groups=groups, in_slope=in_slope, out_slope=out_slope, alpha=alpha, beta=beta,
-                     acc_scale=acc_scale, w_x3=w_x3, ci_pad=ci_pad, in_stride=in_stride, in_phase=in_phase)
+                     acc_scale=acc_scale, w_x3=w_x3, ci_pad=ci_pad, in_stride=in_stride, in_phase=in_phase, x_planes=x_planes)
         self.ops.append(op)
         self.release(tmp)
 
     GN_PREPASS_MIN_CO = 512
+    XT_MIN_CO = 384
+
+    def xt_planes(self, x: int, channels: int, stats: int, gamma, beta_gn, act: int, slope: float, upsample2: int, groups: int = 32) -> int:
+        """x -> new buffer of pre-activated, split-bf16, transposed planes with zero halo rows (VB_OP_XT_PLANES)."""
+        out = self.buf(channels, self.bufs[x][1] * (2 if upsample2 else 1), 3)
+        self.ops.append(L.NetOp(kind=L.OP_XT_PLANES, x=x, out=out, res=-1, stats=stats, w_buf=-1, gn_gamma=self._t(gamma),
+                                gn_beta=self._t(beta_gn), Ci=channels, gn_groups=groups, in_act=act, in_slope=slope, upsample2=upsample2))
+        return out
 
     def gn_apply(self, x: int, channels: int, stats: int, gamma, beta_gn, act: int, groups: int = 32) -> int:
         """x -> new buffer holding GroupNorm(x) (act = ACT_GN) or swish(GroupNorm(x)) (ACT_GN_SWISH)."""
@@ -361,11 +371,11 @@ def _vae_block_builders(nb: "NetBuilder", g: Dict[str, Tensor]):
         split = nb.precision == "split"
         q, k, v = nb.buf(c, tm), nb.buf(c, tm), nb.buf(c, tm)
         gam, bet = g[p + "norm.weight"], g[p + "norm.bias"]
-        xn = nb.gn_apply(x, c, st, gam, bet, L.ACT_GN) if (split and c >= nb.GN_PREPASS_MIN_CO) else -1
+        xn = nb.xt_planes(x, c, st, gam, bet, L.ACT_GN, 0.0, 0) if (split and c >= nb.XT_MIN_CO and c % 32 == 0) else -1
         for name, dst, tr in (("q", q, 1 if split else 0), ("k", k, 0), ("v", v, 0 if split else 1)):
             w, b = cw(p + name)
             if xn >= 0:
-                nb.conv(xn, dst, c, c, w, b, out_transposed=tr)
+                nb.conv(xn, dst, c, c, w, b, out_transposed=tr, x_is_planes=True)
             else:
                 nb.conv(x, dst, c, c, w, b, stats=st, gamma=gam, beta_gn=bet, in_act=L.ACT_GN, out_transposed=tr)
         nb.release(xn)
