@@ -27,6 +27,32 @@ def ctx():
     return Context("cuda:0")
 
 
+def test_c1_one_clip_ten_steps_vs_oracle(ctx):
+    """BASELINE configs[0] - the reference's own CPU-runnable case: ONE 20 s clip (T = 752, L = 80), 10 Euler steps with CFG,
+    VAE decode; the HIP sampler (split precision, injected routing noise) against the pinned CPU oracle at full geometry."""
+    from tests.helpers import gumbel_arrays_steps
+    from versband_amd.engine import DiTEngine, build_vae_decoder
+    dcfg = synth.DiTConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), SEED + 1)
+    B, T, Lc, E, steps, scale = 1, 752, 80, 4, 10, 3.0
+    inp = clip_batch(B, T, Lc)
+    noise_steps = [[exp_noise(B, T, E, 2 * k + br, 4) for br in (0, 1)] for k in range(steps)]
+    eng = DiTEngine(ctx, dcfg, sd, precision="split")
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    idx, dts = vm.euler_tables(steps + 1)
+    assert list(idx) == [0, 100, 200, 300, 400, 500, 600, 700, 800, 900]           # SURVEY 8a A3 golden indices
+    z = eng.sample_cfg(inp["x_latent"], cond, idx, dts, scale, noise=gumbel_arrays_steps(noise_steps))
+    mel = build_vae_decoder(ctx, sdv).run(z)
+    torch.cuda.synchronize()
+    cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
+    cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], inp["midi"], inp["beats"], T)
+    z_ref = ref_cpu.sample_cfg(sd, inp["x_latent"], cc, cu, scale, steps + 1, lambda k, br: noise_steps[k][br])
+    mel_ref = ref_cpu.vae_decode(sdv, z_ref)
+    assert rel_l2(z, z_ref) < 1e-3, describe("10-step latent vs oracle", z, z_ref)
+    assert float((mel.cpu() - mel_ref).abs().mean()) < 1e-3
+
+
 def test_c3_moe_stress_e8_full_size_vs_oracle(ctx):
     """num_experts = 8 (band = 96 channels: K tail of the band GEMMs, 16 routed groups), T = 752, L = 80."""
     from versband_amd.engine import DiTEngine
