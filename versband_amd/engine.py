@@ -6,6 +6,7 @@ compute step of the hot path is a call into libversband_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -280,7 +281,7 @@ class NetBuilder:
         self.release(tmp)
 
     GN_PREPASS_MIN_CO = 512
-    XT_MIN_CO = 384
+    XT_MIN_CO = int(os.environ.get("VB_XT_MIN_CO", "384"))      # (tuning knob; 256 / 128 would pull the wide vocoder stages in)
 
     def xt_planes(self, x: int, channels: int, stats: int, gamma, beta_gn, act: int, slope: float, upsample2: int, groups: int = 32) -> int:
         """x -> new buffer of pre-activated, split-bf16, transposed planes with zero halo rows (VB_OP_XT_PLANES)."""
