@@ -229,6 +229,21 @@ size_t vb_t5_workspace_bytes(const vb_t5_config* cfg, int B, int L);
 /* ids int64 [B][L] -> out f32 [B][L][d_model] */
 int vb_t5_encode(vb_ctx* ctx, const int64_t* ids, int B, int L, float* out, void* ws, void* stream);
 
+/* ------------------------------------------------------------ log-mel front-end ----
+ * MelNet.forward (preprocess/NAT_mel.py:64-86): clamp to [-1, 1]; reflect-pad (n_fft - hop)/2 samples on both sides (:71; when
+ * `center` is set torch.stft reflect-pads the padded signal by n_fft/2 once more); STFT (n_fft, hop; the Hann window - zero-padded to n_fft when win < n_fft - is
+ * folded into the basis); sqrt(re^2 + im^2 + 1e-9); mel_basis @ .; log10(max(., 1e-5)).  n_fft must be a multiple of the hop:
+ * the windowed DFT of all frames then is one convolution over hop-blocks on the exact-fp32 MFMA convolution kernel.
+ *   dft_w   f32 [n_fft/hop][hop][Co4], Co4 = 2*im_off, im_off = roundup(n_fft/2 + 1, 4): column f (< n_fft/2 + 1) = w[n] cos(2 pi f n / n_fft),
+ *           column im_off + f = -w[n] sin(2 pi f n / n_fft), n = tap*hop + c; other columns zero
+ *   basis_t f32 [n_fft/2 + 1][n_mels]  (the mel filterbank, transposed)
+ *   wav f32 [B][L] -> mel f32 [B][n_mels][T] and / or spec f32 [B][T][Co4] (either may be NULL), T = vb_melnet_frames() */
+typedef struct { int n_fft, hop, n_mels; } vb_mel_config;
+int vb_melnet_load(vb_ctx* ctx, const vb_mel_config* cfg, const float* dft_w, const float* basis_t);
+int vb_melnet_frames(const vb_mel_config* cfg, int L, int center);
+size_t vb_melnet_workspace_bytes(const vb_mel_config* cfg, int B, int L, int center);
+int vb_melnet_forward(vb_ctx* ctx, const float* wav, int B, int L, int center, float* mel, float* spec, void* ws, void* stream);
+
 /* ------------------------------------------------------------------- unit kernels ---- */
 /* RMSNorm (flag_large_dit_moe.py:52-77) * w then modulate (:80-81); shift/scale [B][mod_ld] or NULL */
 int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D,

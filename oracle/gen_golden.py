@@ -29,6 +29,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from versband_amd import prng, synth  # noqa: E402
+from oracle import ref_cpu as R  # noqa: E402
 
 GOLD = os.path.join(REPO, "tests", "golden")
 
@@ -483,13 +484,38 @@ def gen_bigvgan(T=8):
     np.savez_compressed(os.path.join(GOLD, "bigvgan.npz"), **out)
 
 
+def gen_melnet():
+    """Log-mel front-end through the reference's own preprocess/NAT_mel.py MelNet.  librosa is absent here: its
+    `filters.mel` import is served by the oracle's restatement (oracle/ref_cpu.py slaney_mel_filterbank), so the fixture pins the
+    clamp / reflect-pad / STFT / magnitude / log10 arithmetic of MelNet.forward, not the filterbank itself."""
+    fm = _mod("librosa.filters", mel=lambda sr, n_fft, n_mels, fmin, fmax: R.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax))
+    _mod("librosa", filters=fm)
+    nat = load_by_path("ref_nat_mel", os.path.join(REF, "preprocess", "NAT_mel.py"))
+    hp = dict(fft_size=1280, audio_num_mel_bins=80, audio_sample_rate=24000, hop_size=320, win_size=1280, fmin=0, fmax=8000)   # mel_spec_24k.py:300-307
+    net = nat.MelNet(hp)
+    out = {"hp_keys": np.array(sorted(hp)), "hp_vals": np.array([hp[k] for k in sorted(hp)], dtype=np.int64)}
+    # (a) noise louder than full scale (exercises the clamp), two clips; (b) a quiet two-tone clip with a silent tail (log floor);
+    # (c) a length that is not a multiple of the hop
+    a = prng.normal(SEED + 900, 2 * 20 * 320).reshape(2, -1) * 0.6
+    t = np.arange(24 * 320, dtype=np.float64) / 24000.0
+    b = (0.2 * np.sin(2 * np.pi * 440.0 * t) + 0.05 * np.sin(2 * np.pi * 3000.0 * t)).astype(np.float32)[None]
+    b[:, 16 * 320:] = 0.0
+    c = prng.normal(SEED + 901, 13 * 320 + 123).reshape(1, -1) * 0.1
+    for tag, wav in (("a", a), ("b", b), ("c", c)):
+        out[f"wav_{tag}"] = wav.astype(np.float32)
+        out[f"mel_{tag}"] = net(torch.from_numpy(wav.astype(np.float32))).numpy()
+    out["mel_basis"] = net.mel_basis.numpy()
+    np.savez_compressed(os.path.join(GOLD, "melnet.npz"), **out)
+    print("melnet", {k: v.shape for k, v in out.items()})
+
+
 def use_reference_paths():
     """Make `import ldm...` / `vocoder...` / `utils...` resolve to the REFERENCE: its packages have no __init__.py (namespace
     packages), so the build's same-named shim packages would win wherever they sit on sys.path.  versband_amd is already
     imported; the repo root (and the cwd entry) leave sys.path and any cached shim modules are dropped."""
     here = {os.path.abspath(p) for p in (REPO, os.getcwd())}
     sys.path[:] = [REF] + [p for p in sys.path if p and os.path.abspath(p) not in here and p != REF]
-    for m in [m for m in sys.modules if m.split(".")[0] in ("ldm", "vocoder", "utils")]:
+    for m in [m for m in sys.modules if m.split(".")[0] in ("ldm", "vocoder", "utils", "preprocess")]:
         if not getattr(sys.modules[m], "__vb_stub__", False):
             del sys.modules[m]
 
@@ -509,6 +535,7 @@ def main():
     gen_fullsize()
     gen_bigvgan()
     gen_t5()
+    gen_melnet()
 
 
 if __name__ == "__main__":

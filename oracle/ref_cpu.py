@@ -602,3 +602,57 @@ def bigvgan_forward(sd: Dict[str, Tensor], hp: dict, mel: Tensor) -> Tensor:
     x = act("activation_post", x)
     x = F.conv1d(x, _hg_w(sd, "conv_post"), sd["conv_post.bias"], padding=3)
     return torch.tanh(x)
+
+
+# ---------------------------------------------------------------------------
+# Log-mel front-end: preprocess/NAT_mel.py:42-86 (MelNet)
+# ---------------------------------------------------------------------------
+
+
+def slaney_mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: Optional[float]):
+    """What NAT_mel.py:53 asks of `librosa.filters.mel(sr=, n_fft=, n_mels=, fmin=, fmax=)` (librosa==0.10.1, requirements.txt:3;
+    NOT in this image - restated from the published algorithm of its defaults htk=False, norm='slaney'; **parity unpinned** for
+    this function alone).  Scalar loops on purpose: the product's numpy version (versband_amd/melnet.py) is written independently."""
+    import numpy as np
+    f_sp, brk, step = 200.0 / 3.0, 1000.0, math.log(6.4) / 27.0
+
+    def to_mel(f):
+        return f / f_sp if f < brk else brk / f_sp + math.log(f / brk) / step
+
+    def to_hz(m):
+        return f_sp * m if m < brk / f_sp else brk * math.exp(step * (m - brk / f_sp))
+
+    fmax = sr / 2.0 if fmax is None else float(fmax)
+    lo, hi = to_mel(float(fmin)), to_mel(fmax)
+    edges = [to_hz(lo + (hi - lo) * i / (n_mels + 1)) for i in range(n_mels + 2)]
+    nb = n_fft // 2 + 1
+    fb = np.zeros((n_mels, nb), dtype=np.float64)
+    for i in range(n_mels):
+        l, c, r = edges[i], edges[i + 1], edges[i + 2]
+        for k in range(nb):
+            f = k * (sr / 2.0) / (nb - 1)
+            v = min((f - l) / (c - l), (r - f) / (r - c))
+            if v > 0.0:
+                fb[i, k] = v * 2.0 / (r - l)
+    return fb.astype(np.float32)
+
+
+def melnet_forward(wav: Tensor, hp: dict, mel_basis: Tensor, center: bool = False) -> Tensor:
+    """MelNet.forward (NAT_mel.py:64-86), complex=False branch: wav [B, L] -> log10-mel [B, n_mels, frames].
+    The STFT is restated as an explicit windowed rFFT of strided frames (float64 accumulate, float32 result)."""
+    n_fft, hop, win = hp["fft_size"], hp["hop_size"], hp["win_size"]
+    y = wav.float().clamp(min=-1.0, max=1.0)                                            # :69
+    p = int((n_fft - hop) / 2)
+    y = F.pad(y.unsqueeze(1), [p, p], mode="reflect").squeeze(1)                        # :71-73
+    if center:                                                                          # torch.stft(center=True, pad_mode='reflect')
+        y = F.pad(y.unsqueeze(1), [n_fft // 2, n_fft // 2], mode="reflect").squeeze(1)
+    window = torch.hann_window(win)
+    if win < n_fft:                                                                     # torch.stft centres a short window
+        left = (n_fft - win) // 2
+        window = F.pad(window, [left, n_fft - win - left])
+    frames = y.unfold(-1, n_fft, hop)                                                   # [B, frames, n_fft]
+    spec = torch.fft.rfft(frames.double() * window.double(), dim=-1)                    # :75-76, onesided, not normalised
+    re, im = spec.real.float(), spec.imag.float()
+    mag = torch.sqrt(re.pow(2) + im.pow(2) + 1e-9)                                      # :81
+    mel = torch.matmul(mel_basis.float(), mag.transpose(1, 2))                          # :82
+    return torch.log10(torch.clamp(mel, min=1e-5))                                      # :83, :26-27

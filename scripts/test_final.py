@@ -11,11 +11,8 @@ One process per GPU (`--num_gpus`, items sharded rank::world like DistributedSam
 from __future__ import annotations
 
 import argparse
-import csv
 import os
 import sys
-import wave
-from pathlib import Path
 
 import numpy as np
 import torch
@@ -27,11 +24,12 @@ if ROOT not in sys.path:
 from ldm.models.diffusion.cfm1_audio_sampler import CFMSampler  # noqa: E402
 from ldm.util import instantiate_from_config  # noqa: E402
 from versband_amd import synth  # noqa: E402
+from versband_amd.harness import (MEL_DOWNSAMPLE, UNIT_FRAMES_MULTIPLE, InferDataset, read_wav, safe_path,  # noqa: E402,F401
+                                  save_rows_to_tsv, write_wav_pcm16)
 from versband_amd.model import load_config, normalize_loudness  # noqa: E402
 from vocoder.hifigan import HifiGAN  # noqa: E402
 
-UNIT_FRAMES_MULTIPLE = 8        # test_final.py:213
-MEL_DOWNSAMPLE = 2              # latent length = int(T_mel / 2)  (:389)
+MEL_HPARAMS = dict(fft_size=1280, audio_num_mel_bins=80, audio_sample_rate=24000, hop_size=320, win_size=1280, fmin=0, fmax=8000)  # preprocess/mel_spec_24k.py:300-307
 
 
 def parse_args():
@@ -53,46 +51,10 @@ def parse_args():
     p.add_argument("--synthetic_frames", type=int, default=1500)
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "split"])
     p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--eval_mel", action="store_true",
+                   help="re-analyse every written accompaniment with the MelNet front-end (HIP) and report mel L1 against the decoded "
+                        "mel and, when the item has one, the ground-truth accompaniment's mel (mel_l1.tsv)")
     return p.parse_args()
-
-
-def pad_or_cut_xd(x: np.ndarray, length: int, dim: int, pad_value=0):
-    """the helper the reference imports but never defines."""
-    n = x.shape[dim]
-    if n >= length:
-        return np.take(x, np.arange(length), axis=dim)
-    pad = [(0, 0)] * x.ndim
-    pad[dim] = (0, length - n)
-    return np.pad(x, pad, constant_values=pad_value)
-
-
-def load_samples_from_tsv(tsv_path):
-    with open(tsv_path) as f:
-        reader = csv.DictReader(f, delimiter="\t", quotechar=None, doublequote=False, lineterminator="\n", quoting=csv.QUOTE_NONE)
-        return [dict(e) for e in reader]
-
-
-class InferDataset:
-    """Intended behaviour of test_final.py:196-340: item -> caption, midi/beats [1,T], length rounded up to 8 frames."""
-
-    def __init__(self, manifest_path, other_condition):
-        self.items = load_samples_from_tsv(manifest_path)
-        self.other = np.load(other_condition, allow_pickle=True).item() if other_condition else {}
-
-    def __len__(self):
-        return len(self.items)
-
-    def __getitem__(self, i):
-        it = self.items[i]
-        name = it.get("name", str(i))
-        extra = self.other.get(name, {})
-        midi = np.asarray(extra.get("midi", np.zeros(1, dtype=np.int64))).reshape(1, -1)
-        beats = np.asarray(extra.get("beats", np.zeros(midi.shape[1], dtype=np.int64))).reshape(1, -1)
-        T = int(np.ceil(midi.shape[1] / UNIT_FRAMES_MULTIPLE) * UNIT_FRAMES_MULTIPLE)
-        midi, beats = pad_or_cut_xd(midi, T, 1, 128), pad_or_cut_xd(beats, T, 1, 2)
-        style = it.get("caption", "").split("<psep>")[0]
-        return {"name": name, "caption": f"Style: {style} Musical: ", "midi": torch.from_numpy(midi).long(),
-                "beats": torch.from_numpy(beats).long(), "acoustic": torch.zeros(20, T), "audio_path": it.get("audio_path")}
 
 
 class SyntheticDataset:
@@ -107,26 +69,6 @@ class SyntheticDataset:
         c = synth.make_clip_inputs(self.seed, i, T_mel // 2, valid_mel=self.frames)
         return {"name": f"synthetic{i:04d}", "caption": c["t5_cond"], "uncond_caption": c["t5_uncond"], "midi": c["midi"],
                 "beats": c["beats"], "acoustic": torch.zeros(20, T_mel), "audio_path": None, "clip": i}
-
-
-def safe_path(path):
-    os.makedirs(Path(path).parent, exist_ok=True)
-    return path
-
-
-def write_wav_pcm16(path, wav, sr):
-    try:
-        import soundfile as sf
-        sf.write(safe_path(path), wav, sr, subtype="PCM_16")
-        return
-    except ImportError:
-        pass
-    pcm = (np.clip(wav, -1.0, 1.0) * 32767.0).astype("<i2")
-    with wave.open(safe_path(path), "wb") as f:
-        f.setnchannels(1)
-        f.setsampwidth(2)
-        f.setframerate(sr)
-        f.writeframes(pcm.tobytes())
 
 
 def initialize_model(args, device):
@@ -157,25 +99,48 @@ def make_vocoder(args, device, tmp_dir):
     return HifiGAN(vocoder_ckpt=tmp_dir, device=device)
 
 
+def _mono(a):
+    a = np.asarray(a, dtype=np.float64)
+    return a if a.ndim == 1 else a.mean(axis=1)
+
+
+def _load_ground_truth(item):
+    """test_final.py:424-427: the vocal stem sits beside the accompaniment with 'accomp' -> 'vocal' in the path.  Returns
+    (gt_vocal, gt_accomp) or (None, None) when the item carries no audio (synthetic items, stripped manifests)."""
+    path = item.get("audio_path")
+    if not path:
+        return None, None
+    try:
+        return _mono(read_wav(path.replace("accomp", "vocal"))[0]), _mono(read_wav(path)[0])
+    except (FileNotFoundError, OSError, ValueError) as e:
+        print(f"no ground-truth audio for {item['name']}: {e}")
+        return None, None
+
+
 @torch.no_grad()
 def gen_song(rank, args):
     device = torch.device(f"cuda:{int(rank)}")
     dataset = SyntheticDataset(args.synthetic, args.synthetic_frames, args.seed) if args.synthetic else \
-        InferDataset(args.manifest_path, args.other_condition)
+        InferDataset(args.manifest_path, args.other_condition, seed=args.seed)
     indices = list(range(len(dataset)))[rank::args.num_gpus]          # DistributedSampler(shuffle=False) sharding
     sampler = initialize_model(args, device)
     vocoder = make_vocoder(args, device, os.path.join(args.save_dir, f".synthetic_vocoder_{rank}"))
+    mel_net = None
+    if args.eval_mel:
+        from preprocess.NAT_mel import MelNet
+        mel_net = MelNet(MEL_HPARAMS, device=device)
     scales = [float(s) for s in args.scales.split("-")] if args.scales else [args.scale]
-    rows = []
+    rows, mel_rows = [], []
     for item_idx, gi in enumerate(indices):
         item = dataset[gi]
         midi, beats, acoustic = item["midi"].to(device), item["beats"].to(device), item["acoustic"].to(device)
         n = args.n_samples
+        cap = item["caption"]
+        generated = {}
         for scale in scales:
             latent_length = int(acoustic.shape[1] / MEL_DOWNSAMPLE)
             embed_dim = sampler.model.first_stage_model.embed_dim
             start_code = torch.randn(n, embed_dim, latent_length, generator=torch.Generator().manual_seed(args.seed + gi)).to(device)
-            cap = item["caption"]
             cond_in = {"caption": torch.stack([cap] * n) if torch.is_tensor(cap) else [cap] * n,
                        "acoustic": {"acoustic": torch.stack([acoustic] * n), "midi": torch.stack([midi] * n).long(),
                                     "beats": torch.stack([beats] * n).long()}, "name": [item["name"]] * n}
@@ -190,19 +155,41 @@ def gen_song(rank, args):
                                       unconditional_guidance_scale=scale, unconditional_conditioning=uc, x_T=start_code,
                                       x_latent=start_code, timesteps=args.ddim_steps + 1, seed=args.seed, clip_base=gi * n)
             mel = sampler.model.decode_first_stage(z)
+            generated[scale] = [(spec, vocoder(spec.transpose(0, 1).cpu())) for spec in mel]
+        gt_vocal, gt_accomp = _load_ground_truth(item)
+        for scale in scales:
             out_dir = os.path.join(args.save_dir, f"cond_gtcodec_accomp_scale_{scale}")
-            for k, spec in enumerate(mel):
-                wav = vocoder(spec.transpose(0, 1).cpu())
+            for k, (spec, wav) in enumerate(generated[scale]):
+                stem = os.path.join(out_dir, f"{rank}-{item_idx:04d}[{k}]")
                 wav = normalize_loudness(wav, -23)
-                path = os.path.join(out_dir, f"{rank}-{item_idx:04d}[{k}][accomp].wav")
-                write_wav_pcm16(path, wav, args.sample_rate)
-                rows.append({"audio_path": path, "caption": cap if isinstance(cap, str) else item["name"], "name": item["name"]})
-    csv_path = safe_path(os.path.join(args.save_dir, f"clap.csv" if args.num_gpus == 1 else f"clap.{rank}.csv"))
-    with open(csv_path, "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=["audio_path", "caption", "name"], delimiter="\t")
-        w.writeheader()
-        w.writerows(rows)
-    print(f"[rank {rank}] wrote {len(rows)} wav files, {csv_path}")
+                if gt_vocal is not None:                                            # :430-457
+                    min_length = min(wav.shape[0], gt_vocal.shape[0])
+                    wav = wav[:min_length]
+                    gt_vocal = normalize_loudness(gt_vocal, -23)[:min_length]
+                    gt_accomp = normalize_loudness(gt_accomp, -23)
+                    write_wav_pcm16(stem + "[gt_vocal].wav", gt_vocal, args.sample_rate)
+                    write_wav_pcm16(stem + "[song].wav", wav[:min_length] + gt_vocal[:min_length], args.sample_rate)
+                    write_wav_pcm16(stem + "[gt_accomp].wav", gt_accomp, args.sample_rate)
+                write_wav_pcm16(stem + "[accomp].wav", wav, args.sample_rate)
+                rows.append({"audio_path": stem + "[accomp].wav", "caption": cap if isinstance(cap, str) else item["name"], "name": item["name"]})
+                if mel_net is not None:
+                    back = mel_net(np.asarray(wav, dtype=np.float32))[0]            # [80, frames] of the written accompaniment
+                    # loudness normalisation is a gain g: log10-mel shifts by log10(g) in every bin - remove the mean offset
+                    f = min(back.shape[1], spec.shape[1])
+                    d = back[:, :f] - spec[:, :f].to(back.device)
+                    row = {"name": item["name"], "scale": scale, "sample": k, "mel_l1_vs_decoded": float((d - d.mean()).abs().mean())}
+                    if gt_accomp is not None:
+                        ref = mel_net(np.asarray(gt_accomp, dtype=np.float32))[0]
+                        f = min(back.shape[1], ref.shape[1])
+                        row["mel_l1_vs_gt_accomp"] = float((back[:, :f] - ref[:, :f]).abs().mean())
+                    mel_rows.append(row)
+    tag = "" if args.num_gpus == 1 else f".{rank}"
+    csv_path = os.path.join(args.save_dir, f"clap{tag}.csv")
+    save_rows_to_tsv(rows, ["audio_path", "caption", "name"], csv_path)                 # :459-462
+    if mel_rows:
+        save_rows_to_tsv(mel_rows, ["name", "scale", "sample", "mel_l1_vs_decoded", "mel_l1_vs_gt_accomp"],
+                         os.path.join(args.save_dir, f"mel_l1{tag}.tsv"))
+    print(f"[rank {rank}] wrote {len(rows)} generated clips, {csv_path}")
 
 
 if __name__ == "__main__":

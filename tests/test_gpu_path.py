@@ -384,3 +384,77 @@ def test_full_size_properties(ctx, engines):
     wav = build_hifigan(ctx, sdh, hcfg.as_hparams()).run(mel[:1])
     torch.cuda.synchronize()
     assert wav.shape == (1, 1, 2 * T * 320) and torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+
+
+# ---------------------------------------------------------------- log-mel front-end
+def _test_audio(B, n, seed):
+    """seeded clip: a few drifting partials + noise, louder than full scale in places (the clamp must act)"""
+    t = np.arange(n, dtype=np.float64) / 24000.0
+    out = []
+    for b in range(B):
+        f0 = 110.0 * (b + 2)
+        y = sum(0.3 / (k + 1) * np.sin(2 * np.pi * f0 * (k + 1) * t * (1.0 + 0.01 * np.sin(2 * np.pi * 0.3 * t))) for k in range(6))
+        y = y * (0.6 + 0.9 * np.sin(2 * np.pi * 0.5 * t) ** 2) + 0.05 * synth.prng.normal(seed + b, n)
+        out.append(y)
+    return torch.from_numpy(np.stack(out).astype(np.float32))
+
+
+def test_melnet_vs_golden_and_oracle():
+    """MelNet on the HIP library (frames kernel -> fp32 MFMA hop-block convolution -> mel tail) against the reference's own MelNet
+    outputs (tests/golden/melnet.npz) and, at BASELINE length (20 s, 1500 frames) and on ragged / centred inputs, the oracle."""
+    from tests.test_oracle_golden import MEL_HP, mel_close
+    from versband_amd._lib import VersbandError
+    from versband_amd.melnet import MelNet
+    g = np.load(os.path.join(GOLD, "melnet.npz"))
+    net = MelNet(MEL_HP)
+    with pytest.raises(VersbandError):
+        net(torch.zeros(1, 6400))                       # no CPU path
+    net.to("cuda:0")
+    assert np.array_equal(net.mel_basis.cpu().numpy(), g["mel_basis"])
+    fb = net.mel_basis.cpu()
+    for tag, tol in (("a", 1e-5), ("b", 1e-2), ("c", 1e-5)):
+        out = net(torch.from_numpy(g["wav_" + tag]))
+        torch.cuda.synchronize()
+        mel_close(out.cpu().numpy(), g["mel_" + tag], tol)
+    # numpy 1-D input, like the reference accepts
+    out = net(g["wav_c"][0])
+    mel_close(out.cpu().numpy(), g["mel_c"], 1e-5)
+    # BASELINE length, 3 clips (odd batch), 20 s + a ragged tail
+    wav = _test_audio(3, 1500 * 320 + 77, 77)
+    assert float(wav.abs().max()) > 1.0
+    out = net(wav)
+    torch.cuda.synchronize()
+    ref = ref_cpu.melnet_forward(wav, MEL_HP, fb)
+    assert out.shape == ref.shape == (3, 80, 1500) and net.frames(wav.shape[1]) == 1500
+    mel_close(out.cpu().numpy(), ref.numpy(), 1e-3)
+    # torch.stft(center=True) geometry
+    short = wav[:2, :40 * 320]
+    outc = net(short, center=True)
+    refc = ref_cpu.melnet_forward(short, MEL_HP, fb, center=True)
+    assert outc.shape == refc.shape == (2, 80, 44)
+    mel_close(outc.cpu().numpy(), refc.numpy(), 1e-3)
+    # complex spectrum [B, T, n_fft/2+1, 2]
+    sp = net(short, complex=True)
+    y = torch.nn.functional.pad(short.clamp(-1, 1).unsqueeze(1), [480, 480], mode="reflect").squeeze(1)
+    fr = y.unfold(-1, 1280, 320).double() * torch.hann_window(1280).double()
+    rs = torch.view_as_real(torch.fft.rfft(fr, dim=-1))
+    assert sp.shape == rs.shape == (2, 40, 641, 2)
+    assert float((sp.cpu().double() - rs).abs().max()) <= 1e-5 * float(rs.abs().max())
+    # loud failure on an input shorter than the reflect padding
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 300))
+
+
+def test_melnet_closes_the_loop_on_the_vocoder(ctx):
+    """Harness-level use (scripts/test_final.py --eval_mel): the mel of a vocoded clip has the frame count of the mel that was
+    vocoded, is finite and sits above the log floor - the shape contract `mel L1 against real audio` relies on."""
+    from versband_amd.engine import build_hifigan
+    from tests.test_oracle_golden import MEL_HP
+    from versband_amd.melnet import MelNet
+    hcfg = synth.HifiGanConfig()
+    sdh = synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2)
+    mel = torch.from_numpy(synth.prng.uniform(5, 2 * 80 * 64, -4.0, 0.5).reshape(2, 80, 64).astype(np.float32))
+    wav = build_hifigan(ctx, sdh, hcfg.as_hparams()).run(mel)
+    back = MelNet(MEL_HP, device="cuda:0")(wav[:, 0])
+    torch.cuda.synchronize()
+    assert back.shape == mel.shape and torch.isfinite(back).all() and float(back.min()) >= -5.0

@@ -157,3 +157,117 @@ def test_longform_window_plan_and_crossfade_partition_of_unity():
     parts = [torch.full((1, 1, n), float(i)) for i, (_, n) in enumerate(plan)]
     out = longform.crossfade_windows(parts, plan, 4500)
     assert float(out[0, 0, 200]) == 0.0 and float(out[0, 0, plan[1][0] + 700]) == 1.0
+
+
+# ---------------------------------------------------------------- harness I/O
+def _write_manifest(tmp_path, rows):
+    cols = ["name", "duration", "caption", "key", "key_confidence", "avg_pitch", "tempo", "tempo_confidence", "emotion", "wav_len",
+            "mel_path", "vocal_mel_path", "audio_path"]
+    p = tmp_path / "total.tsv"
+    with open(p, "w") as f:
+        f.write("\t".join(cols) + "\n")
+        for r in rows:
+            f.write("\t".join(str(r[c]) for c in cols) + "\n")
+    return str(p)
+
+
+def _make_items(tmp_path, lengths, vocal_lengths=None, durations=None):
+    rows, midi, beats = [], {}, {}
+    rs = np.random.RandomState(0)
+    for i, T in enumerate(lengths):
+        name = f"song{i:02d}"
+        np.save(tmp_path / f"{name}_mel.npy", rs.uniform(-5, 1, (80, T)).astype(np.float32))
+        Tv = (vocal_lengths or lengths)[i]
+        np.save(tmp_path / f"{name}_vocal_mel.npy", rs.uniform(-5, 1, (80, Tv)).astype(np.float32))
+        midi[name] = rs.randint(0, 129, T)
+        beats[name] = rs.randint(0, 2, T)
+        rows.append(dict(name=name, duration=(durations or [T / 75.0] * len(lengths))[i], caption="warm pop<psep>soft rock", key="C major",
+                         key_confidence=0.9, avg_pitch=60.0, tempo=100.0, tempo_confidence=0.8, emotion="['happy', 'calm', 'bright']",
+                         wav_len=T / 75.0, mel_path=str(tmp_path / f"{name}_mel.npy"), vocal_mel_path=str(tmp_path / f"{name}_vocal_mel.npy"),
+                         audio_path=str(tmp_path / f"{name}_accomp.wav")))
+    np.save(tmp_path / "midi.npy", midi, allow_pickle=True)
+    np.save(tmp_path / "beats.npy", beats, allow_pickle=True)
+    return _write_manifest(tmp_path, rows), str(tmp_path / "midi.npy"), midi, beats
+
+
+def test_infer_dataset_items(tmp_path):
+    """scripts/test_final.py:196-340: lengths round up to 8 frames, acoustic = first 20 vocal-mel rows padded with -5, midi / beats
+    cropped to the mel and padded with 0, captions 'Style: .. Musical: ..', items longer than 20 s dropped, corrupted inputs replaced."""
+    from versband_amd.harness import InferDataset
+    manifest, midi_path, midi, beats = _make_items(tmp_path, [301, 750, 1600, 200], vocal_lengths=[301, 752, 1600, 120],
+                                                   durations=[4.0, 10.0, 21.3, 2.7])
+    ds = InferDataset(manifest, midi_path, seed=3)
+    assert len(ds) == 3 and sorted(i["name"] for i in ds.items) == ["song00", "song01", "song03"]     # song02 is > 20 s
+    by_name = {ds.items[i]["name"]: ds[i] for i in range(len(ds))}
+    a = by_name["song00"]
+    assert a["acoustic"].shape == (20, 304) and a["image"].shape == (80, 304) and a["midi"].shape == a["beats"].shape == (1, 304)
+    vm_ = np.load(tmp_path / "song00_vocal_mel.npy")
+    assert torch.equal(a["acoustic"][:, :301], torch.from_numpy(vm_[:20])) and float(a["acoustic"][:, 301:].max()) == -5.0
+    assert torch.equal(a["midi"][0, :301].long(), torch.from_numpy(midi["song00"]).long()) and float(a["midi"][0, 301:].abs().max()) == 0.0
+    assert torch.equal(a["beats"][0, :301].long(), torch.from_numpy(beats["song00"]).long())
+    assert float(a["image"][:, 301:].max()) == -5.0 and a["audio_path"].endswith("song00_accomp.wav")
+    assert a["caption"].startswith("Style: ") and " Musical: " in a["caption"] and a["ori_caption"] in ("Style: warm pop ", "Style: soft rock ")
+    b = by_name["song01"]            # vocal mel 2 frames longer than the mel: cropped to the mel length, then rounded up to 752
+    assert b["acoustic"].shape == (20, 752) and torch.equal(b["acoustic"][:, :750], torch.from_numpy(np.load(tmp_path / "song01_vocal_mel.npy")[:20, :750]))
+    c = by_name["song03"]            # vocal mel 80 frames short: declared corrupted -> pad values 128 / 2 / -5 (:282-286)
+    assert c["acoustic"].shape == (20, 200) and float(c["acoustic"].max()) == -5.0
+    assert float(c["midi"].min()) == 128.0 and float(c["beats"].min()) == 2.0
+    os.remove(tmp_path / "song00_mel.npy")      # unreadable mel: 75 frames of floor (:270-277) -> the vocal mel no longer matches
+    d = ds[[i for i in range(len(ds)) if ds.items[i]["name"] == "song00"][0]]
+    assert d["image"].shape == (80, 80) and float(d["image"].max()) == -5.0
+    with pytest.raises(FileNotFoundError):
+        InferDataset(str(tmp_path / "missing.tsv"), midi_path)
+
+
+def test_caption_generator_rules():
+    """Decision rules of CaptionGenerator2 (caption_generator.py:781-837, :612-670): confidence gates, dead zones, key naming."""
+    import random
+    from versband_amd.harness import CaptionGenerator2
+    g = CaptionGenerator2(random.Random(0))
+    assert g.prepare_tempo(100, 0.2) is None and g.prepare_tempo(0, 0.9) is None
+    assert g.prepare_tempo(60, 0.9) == "very slow" and g.prepare_tempo(170, 0.9) == "very fast"
+    assert g.prepare_tempo(70, 0.9) is None and g.prepare_tempo(90, 0.9) is None and g.prepare_tempo(160, 0.9) is None     # dead zones
+    assert g.prepare_tempo(100, 0.9) in ("medium", "moderate") and g.prepare_tempo(130, 0.9) in ("fast", "quick")
+    assert g.prepare_avg_pitch(50) in ("low", "relatively low") and g.prepare_avg_pitch(54) is None and g.prepare_avg_pitch(80) == "very high"
+    assert g.prepare_avg_pitch(-1) is None and g.prepare_avg_pitch(63) is None and g.prepare_avg_pitch(70) in ("high", "relatively high")
+    assert g.prepare_key("C major", 0.4) is None and g.prepare_key("None", 0.9) is None
+    assert {g.prepare_key("C major", 0.9) for _ in range(40)} == {"C major", "A minor"}
+    assert {g.prepare_key("f#", 0.9) for _ in range(40)} == {"F-sharp minor", "A major"}
+    assert {g.prepare_key("B-", 0.9) for _ in range(40)} == {"B-flat major", "G minor"}
+    assert g.prepare_emotion([]) is None and g.prepare_emotion(["sad"]) == "sad"
+    e3 = g.prepare_emotion(["a", "b", "c"])
+    assert e3.count(", ") == 2 and ", and " in e3 and sorted(e3.replace(", and ", ", ").split(", ")) == ["a", "b", "c"]
+    durs = {g.prepare_duration(12.2) for _ in range(40)}
+    assert durs == {"a long time", "12 seconds"} and {g.prepare_duration(5.0) for _ in range(40)} == {None, "5 seconds"}
+    full = g.transcribe(key="G major", key_conf=0.9, avg_pitch=70, tempo=130, tempo_conf=0.9, emotion=["tense"], duration=18.0)
+    assert full.startswith("The melody is in ") and "pitch" in full and "tempo" in full and full.endswith("It carries a tense mood.")
+    assert g.transcribe() == "" and g.transcribe(emotion=["calm"]) == "It carries a calm mood."
+
+
+def test_wav_and_tsv_round_trip(tmp_path):
+    from versband_amd.harness import load_samples_from_tsv, pad_or_cut_xd, read_wav, save_rows_to_tsv, write_wav_pcm16
+    t = np.arange(2400) / 24000.0
+    wav = 0.5 * np.sin(2 * np.pi * 440 * t)
+    wav[:3] = [1.5, -1.5, 0.999999]                                       # clipping
+    p = str(tmp_path / "sub" / "a[0][accomp].wav")
+    write_wav_pcm16(p, wav, 24000)
+    back, sr = read_wav(p)
+    assert sr == 24000 and back.shape == wav.shape and back.dtype == np.float64
+    assert back[0] == 32767 / 32768 and back[1] == -1.0 and np.abs(back[3:] - wav[3:]).max() <= 0.5 / 32768 + 1e-12
+    rows = [{"audio_path": p, "caption": "Style: pop Musical: The melody is in C major.", "name": "x"}, {"audio_path": "q", "caption": "", "name": "y"}]
+    save_rows_to_tsv(rows, ["audio_path", "caption", "name"], tmp_path / "clap.csv")
+    assert load_samples_from_tsv(tmp_path / "clap.csv") == rows
+    x = np.arange(12).reshape(2, 6)
+    assert pad_or_cut_xd(x, 4, 1).tolist() == [[0, 1, 2, 3], [6, 7, 8, 9]] and pad_or_cut_xd(x, 8, 1, -5)[0].tolist() == [0, 1, 2, 3, 4, 5, -5, -5]
+    xt = pad_or_cut_xd(torch.ones(2, 3), 5, dim=1, pad_value=2.0)
+    assert torch.is_tensor(xt) and xt.shape == (2, 5) and xt[0].tolist() == [1, 1, 1, 2, 2]
+
+
+def test_reference_import_paths_of_the_mel_front_end():
+    from preprocess.NAT_mel import MelNet
+    from versband_amd import melnet
+    assert MelNet is melnet.MelNet
+    net = MelNet(dict(fft_size=1280, audio_num_mel_bins=80, audio_sample_rate=24000, hop_size=320, win_size=1280, fmin=0, fmax=8000))
+    assert net.mel_basis.shape == (80, 641) and net.hann_window.shape == (1280,) and net.frames(480000) == 1500 and net.frames(480000, center=True) == 1504
+    with pytest.raises(ValueError):
+        MelNet(dict(fft_size=1024, audio_num_mel_bins=80, audio_sample_rate=24000, hop_size=300, win_size=1024, fmin=0, fmax=8000))

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import ref_cpu
 from tests.helpers import check_digest, clip_batch, exp_noise
@@ -158,3 +159,73 @@ def test_bigvgan_matches_reference(golden_dir, tag):
     sd = synth.make_state_dict(synth.bigvgan_shapes(cfg), SEED + 7)
     wav = ref_cpu.bigvgan_forward(sd, cfg.as_hparams(), torch.from_numpy(g[tag + "_mel"]))
     assert _rel(wav, g[tag + "_wav"]) < 1e-5
+
+
+# ---------------------------------------------------------------- log-mel front-end
+MEL_HP = dict(fft_size=1280, audio_num_mel_bins=80, audio_sample_rate=24000, hop_size=320, win_size=1280, fmin=0, fmax=8000)
+
+
+def mel_close(got, ref, log_tol):
+    """log10-mel comparison: tight in the linear domain (the quantity the STFT produces), `log_tol` in the log domain - spectral
+    leakage bins 5 decades under the peak amplify the 1e-7-relative noise of ANY fp32 transform (the reference's FFT included)."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    lin = np.abs(10.0 ** got - 10.0 ** ref).max()
+    peak = (10.0 ** ref).max()
+    assert lin <= 5e-6 + 2e-6 * peak, f"linear mel error {lin:.3e} (peak {peak:.3g})"
+    assert np.abs(got - ref).max() <= log_tol, f"log10-mel error {np.abs(got - ref).max():.3e} > {log_tol}"
+
+
+def test_melnet_oracle_matches_reference_golden(golden_dir):
+    g = _load(golden_dir, "melnet.npz")
+    assert dict(zip(g["hp_keys"].tolist(), g["hp_vals"].tolist())) == MEL_HP
+    fb = ref_cpu.slaney_mel_filterbank(24000, 1280, 80, 0, 8000)
+    assert np.array_equal(fb, g["mel_basis"])
+    for tag, tol in (("a", 1e-5), ("b", 5e-3), ("c", 1e-5)):
+        out = ref_cpu.melnet_forward(torch.from_numpy(g["wav_" + tag]), MEL_HP, torch.from_numpy(fb))
+        mel_close(out.numpy(), g["mel_" + tag], tol)
+    assert g["mel_b"][:, :, 20:].max() == -5.0          # silent tail sits on the log floor
+    assert g["mel_c"].shape[-1] == g["wav_c"].shape[-1] // 320
+
+
+def test_mel_filterbank_restatements_agree_and_known_answers():
+    """The two independent restatements of librosa.filters.mel (oracle: scalar loops; product: numpy) agree; known answers: the
+    librosa documentation's example `mel(sr=22050, n_fft=2048)` prints row 0 as [0., 0.016, 0.032, ...] (3 decimals); Slaney
+    normalisation makes every filter integrate to ~1 over frequency; a filter is zero outside its two neighbours' centres."""
+    from versband_amd import melnet as M
+    for sr, n_fft, n_mels, fmin, fmax in ((24000, 1280, 80, 0, 8000), (22050, 2048, 128, 0, None), (16000, 1024, 40, 55, 7600)):
+        a = ref_cpu.slaney_mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        b = M.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        assert a.shape == b.shape == (n_mels, n_fft // 2 + 1) and a.dtype == b.dtype == np.float32
+        assert np.abs(a - b).max() <= 1e-8
+        df = sr / n_fft
+        area = a.astype(np.float64).sum(1) * df
+        wide = area[n_mels // 2:]                       # filters several bins wide: the Riemann sum is close to the integral
+        assert np.all(np.abs(wide - 1.0) < 0.08), wide
+        assert (a >= 0).all() and (a.sum(1) > 0).all()
+    doc = ref_cpu.slaney_mel_filterbank(22050, 2048, 128, 0.0, None)
+    assert [round(float(v), 3) for v in doc[0, :3]] == [0.0, 0.016, 0.032]
+    assert doc[0, -1] == 0.0 and doc[-1, 0] == 0.0
+
+
+def test_melnet_dft_weights_as_hop_block_convolution(golden_dir):
+    """The product's weight layout (vb_melnet_load): the windowed DFT as a k = n_fft/hop convolution over hop-blocks reproduces the
+    reference MelNet on CPU (torch conv1d standing in for the HIP convolution kernel)."""
+    from versband_amd import melnet as M
+    g = _load(golden_dir, "melnet.npz")
+    W = torch.from_numpy(M.dft_weights(1280, 320, 1280))
+    assert W.shape == (4, 320, 2 * M.im_offset(1280)) and M.im_offset(1280) == 644
+    assert float(W[:, :, 641:644].abs().max()) == 0.0 and float(W[:, :, 644 + 641:].abs().max()) == 0.0
+    fb = torch.from_numpy(M.mel_filterbank(24000, 1280, 80, 0, 8000))
+    for tag, tol in (("a", 1e-5), ("b", 1e-2), ("c", 1e-5)):
+        y = torch.from_numpy(g["wav_" + tag]).clamp(-1, 1)
+        y = F.pad(y.unsqueeze(1), [480, 480], mode="reflect").squeeze(1)
+        T = y.shape[1] // 320 - 3
+        X = y[:, :(T + 3) * 320].reshape(y.shape[0], T + 3, 320).transpose(1, 2)
+        sp = F.conv1d(X, W.permute(2, 1, 0).contiguous())
+        re, im = sp[:, :641], sp[:, 644:644 + 641]
+        mel = torch.log10(torch.clamp(torch.matmul(fb, torch.sqrt(re ** 2 + im ** 2 + 1e-9)), min=1e-5))
+        mel_close(mel.numpy(), g["mel_" + tag], tol)
+    # short window: centred zero-padding like torch.stft
+    w = M.hann_window(800, 1280)
+    assert w[:240].max() == 0.0 and w[1040:].max() == 0.0 and abs(w[240 + 400] - 1.0) < 1e-6

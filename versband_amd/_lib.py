@@ -60,6 +60,10 @@ class Noise(C.Structure):
     _fields_ = [("g1", c_void_p), ("g2", c_void_p), ("g3", c_void_p), ("seed", c_u64), ("clip_base", c_i64), ("nfe", c_int)]
 
 
+class MelConfig(C.Structure):
+    _fields_ = [("n_fft", c_int), ("hop", c_int), ("n_mels", c_int)]
+
+
 class BufDesc(C.Structure):
     _fields_ = [("channels", c_int), ("tmul", c_int), ("square", c_int)]
 
@@ -102,6 +106,10 @@ PROTOTYPES = {
     "vb_t5_workspace_bytes": (C.c_size_t, [C.POINTER(T5Config), c_int, c_int]),
     "vb_t5_encode": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_hifigan_forward": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_melnet_load": (c_int, [P, C.POINTER(MelConfig), P, P]),
+    "vb_melnet_frames": (c_int, [C.POINTER(MelConfig), c_int, c_int]),
+    "vb_melnet_workspace_bytes": (C.c_size_t, [C.POINTER(MelConfig), c_int, c_int, c_int]),
+    "vb_melnet_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P]),
     "vb_rmsnorm_modulate": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_float, P, c_int, P]),
     "vb_router_top1": (c_int, [P, P, c_int, c_int, P, P]),
     "vb_route_bucket_scratch_ints": (c_int, [c_int, c_int]),

@@ -64,6 +64,9 @@ struct vb_ctx {
     bool t5_loaded = false;
     vb_t5_config t5cfg;
     vb_t5_weights t5w;
+    bool mel_loaded = false;
+    vb_mel_config melcfg;
+    const float* mel_dft = nullptr; const float* mel_basis_t = nullptr;
 };
 
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -765,6 +768,51 @@ int vb_t5_encode(vb_ctx* ctx, const int64_t* ids, int B, int L, float* out, void
     }
     VB_TRY(launch_rmsnorm_mod(s.h, w.final_ln, nullptr, nullptr, 0, R, D, L, c.eps, nrm, st));
     VB_TRY(launch_planes_to_f32(nrm, (int64_t)R * D, out, st));
+    return VB_OK;
+}
+
+// ---- log-mel front-end ------------------------------------------------------------------------------
+static inline int mel_im_off(const vb_mel_config& c) { return (c.n_fft / 2 + 1 + 3) / 4 * 4; }
+struct MelWs { float* X; float* spec; int T, J, pad, pad2; size_t total; };
+static MelWs carve_mel(void* base, const vb_mel_config& c, int B, int L, int center) {
+    MelWs o;
+    Carver cv(base);
+    o.pad = (c.n_fft - c.hop) / 2; o.pad2 = center ? c.n_fft / 2 : 0;
+    const int pad = o.pad + o.pad2;
+    o.T = L + 2 * pad >= c.n_fft ? 1 + (L + 2 * pad - c.n_fft) / c.hop : 0;
+    o.J = o.T + c.n_fft / c.hop - 1;
+    o.X = cv.take<float>((size_t)B * c.hop * o.J);
+    o.spec = cv.take<float>((size_t)B * o.T * 2 * mel_im_off(c));
+    o.total = cv.off;
+    return o;
+}
+int vb_melnet_load(vb_ctx* ctx, const vb_mel_config* cfg, const float* dft_w, const float* basis_t) {
+    if (!ctx || !cfg || !dft_w || !basis_t) VB_FAIL(VB_E_INVALID, "melnet_load: null argument");
+    if (cfg->hop < 1 || cfg->n_fft < cfg->hop || cfg->n_fft % cfg->hop || cfg->n_fft % 2 || (cfg->n_fft - cfg->hop) % 2)
+        VB_FAIL(VB_E_INVALID, "melnet_load: n_fft %d must be an even multiple of the hop %d (and n_fft - hop even)", cfg->n_fft, cfg->hop);
+    if (cfg->n_fft / cfg->hop - 1 > 64) VB_FAIL(VB_E_INVALID, "melnet_load: n_fft / hop = %d too large", cfg->n_fft / cfg->hop);
+    if (cfg->n_mels < 1 || cfg->n_mels > 256) VB_FAIL(VB_E_INVALID, "melnet_load: n_mels %d", cfg->n_mels);
+    ctx->melcfg = *cfg; ctx->mel_dft = dft_w; ctx->mel_basis_t = basis_t; ctx->mel_loaded = true;
+    return VB_OK;
+}
+int vb_melnet_frames(const vb_mel_config* cfg, int L, int center) { return cfg ? carve_mel(nullptr, *cfg, 1, L, center).T : 0; }
+size_t vb_melnet_workspace_bytes(const vb_mel_config* cfg, int B, int L, int center) { return cfg ? carve_mel(nullptr, *cfg, B, L, center).total : 0; }
+int vb_melnet_forward(vb_ctx* ctx, const float* wav, int B, int L, int center, float* mel, float* spec, void* ws, void* stream) {
+    if (!ctx || !ctx->mel_loaded) VB_FAIL(VB_E_STATE, "melnet_forward: front-end not loaded");
+    if (!wav || !ws || (!mel && !spec) || B < 1) VB_FAIL(VB_E_INVALID, "melnet_forward: bad argument");
+    VB_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const vb_mel_config& c = ctx->melcfg;
+    MelWs s = carve_mel(ws, c, B, L, center);
+    if (s.T < 1) VB_FAIL(VB_E_INVALID, "melnet_forward: %d samples (+ 2 x %d) are shorter than one %d-sample frame", L, s.pad + s.pad2, c.n_fft);
+    const int nb = c.n_fft / 2 + 1, im_off = mel_im_off(c), Co4 = 2 * im_off;
+    float* sp = spec ? spec : s.spec;
+    VB_TRY(launch_stft_frames(wav, B, L, c.hop, s.pad, s.pad2, s.J, s.X, st));
+    ConvArgs a;
+    a.x = s.X; a.x_bstride = (int64_t)c.hop * s.J; a.Ci = c.hop; a.T_in = s.J; a.w = ctx->mel_dft; a.Co = Co4; a.ksize = c.n_fft / c.hop;
+    a.dil = 1; a.pad = 0; a.out = sp; a.out_bstride = (int64_t)s.T * Co4; a.T_out = s.T; a.out_transposed = 1; a.B = B;
+    VB_TRY(launch_conv1d(a, st));
+    if (mel) VB_TRY(launch_mel_tail(sp, B, s.T, Co4, nb, im_off, ctx->mel_basis_t, c.n_mels, mel, st));
     return VB_OK;
 }
 

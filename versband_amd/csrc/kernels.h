@@ -132,6 +132,9 @@ int launch_t5_attention(Planes qkv, const float* pos_bias, int pos_len, int B, i
 static inline int xt_rows(int T_eff) { return T_eff + XT_HEAD + XT_TAIL; }
 int launch_xt_planes(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups, int act,
                      float slope, int upsample2, int B, int C, int T_in, bf16_t* out, hipStream_t st);
+// log-mel front-end (melnet.hip)
+int launch_stft_frames(const float* wav, int B, int L, int hop, int pad, int pad2, int J, float* X, hipStream_t st);
+int launch_mel_tail(const float* spec, int B, int T, int Co4, int nb, int im_off, const float* basisT, int n_mels, float* mel, hipStream_t st);
 int launch_aa_act(const float* x, const float* alpha, const float* inv_beta, const float* filt, int B, int C, int T, float* out, hipStream_t st);
 int launch_gn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int B, int C, int T,
                     int groups, int swish, float* out, hipStream_t st);
