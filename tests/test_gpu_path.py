@@ -394,7 +394,7 @@ def _test_audio(B, n, seed):
     for b in range(B):
         f0 = 110.0 * (b + 2)
         y = sum(0.3 / (k + 1) * np.sin(2 * np.pi * f0 * (k + 1) * t * (1.0 + 0.01 * np.sin(2 * np.pi * 0.3 * t))) for k in range(6))
-        y = y * (0.6 + 0.9 * np.sin(2 * np.pi * 0.5 * t) ** 2) + 0.05 * synth.prng.normal(seed + b, n)
+        y = 1.6 * y * (0.6 + 0.9 * np.sin(2 * np.pi * 0.5 * t) ** 2) + 0.05 * synth.prng.normal(seed + b, n)
         out.append(y)
     return torch.from_numpy(np.stack(out).astype(np.float32))
 
@@ -410,7 +410,7 @@ def test_melnet_vs_golden_and_oracle():
     with pytest.raises(VersbandError):
         net(torch.zeros(1, 6400))                       # no CPU path
     net.to("cuda:0")
-    assert np.array_equal(net.mel_basis.cpu().numpy(), g["mel_basis"])
+    assert np.abs(net.mel_basis.cpu().numpy() - g["mel_basis"]).max() <= 1e-8       # two independent restatements of the filterbank
     fb = net.mel_basis.cpu()
     for tag, tol in (("a", 1e-5), ("b", 1e-2), ("c", 1e-5)):
         out = net(torch.from_numpy(g["wav_" + tag]))
