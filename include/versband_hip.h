@@ -101,6 +101,8 @@ typedef struct {
     const float* midi_conv_w; const float* midi_conv_b;    /* packed [5][D][D] */
     const float* beats_conv_w; const float* beats_conv_b;
     const float* final_proj_w; const float* final_proj_b;  /* packed [1][D][D] */
+    const void* midi_conv_w3; const void* beats_conv_w3; const void* final_proj_w3;   /* optional: the three stem convolutions' weights as
+                                                              split-bf16 planes [2][taps][D][D] (bf16x3 conv kernel instead of exact fp32) */
     const void* c_emb0; const float* c_emb0_b;             /* planes(2) [D][ori] */
     const void* c_emb2; const float* c_emb2_b;             /* planes(2) [D][D] */
     const float* c_ln_w; const float* c_ln_b;

@@ -31,7 +31,7 @@ class DitBlockWeights(C.Structure):
 
 TOP_FIELDS = ["t_freq_table", "t_mlp0_w", "t_mlp0_b", "t_mlp2_w", "t_mlp2_b", "adaln_w", "adaln_b", "adaln_wp", "hl_w", "hl_b",
               "proj_in_w", "proj_in_b", "proj_in_w3", "final_w", "final_b", "final_wp", "rope_cos", "rope_sin", "midi_emb", "beats_emb",
-              "midi_conv_w", "midi_conv_b", "beats_conv_w", "beats_conv_b", "final_proj_w", "final_proj_b",
+              "midi_conv_w", "midi_conv_b", "beats_conv_w", "beats_conv_b", "final_proj_w", "final_proj_b", "midi_conv_w3", "beats_conv_w3", "final_proj_w3",
               "c_emb0", "c_emb0_b", "c_emb2", "c_emb2_b", "c_ln_w", "c_ln_b", "cap_ln_w", "cap_ln_b", "cap_lin_w", "cap_lin_b"]
 
 

@@ -231,12 +231,16 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
         cv.w = which ? w.beats_conv_w : w.midi_conv_w; cv.bias = which ? w.beats_conv_b : w.midi_conv_b;
         cv.Co = D; cv.ksize = 5; cv.pad = 2; cv.out = which ? s.tC : s.tB; cv.out_bstride = (int64_t)D * T_mel; cv.T_out = T_mel;
         cv.out_act = ACT_LRELU; cv.out_slope = 0.01f; cv.B = B;
+        if (const void* w3 = which ? w.beats_conv_w3 : w.midi_conv_w3; w3 && D % 32 == 0 && !getenv("VB_STEM_F32")) {
+            cv.wp = (const bf16_t*)w3; cv.Ci_pad = D; cv.wp_plane = (int64_t)5 * D * D;
+        }
         VB_TRY(launch_conv1d(cv, st));
     }
     VB_TRY(launch_pool_add(s.tB, s.tC, B, D, T_mel, s.tD, st));
     cv = ConvArgs();
     cv.x = s.tD; cv.x_bstride = (int64_t)D * T_ac; cv.Ci = D; cv.T_in = T_ac; cv.w = w.final_proj_w; cv.bias = w.final_proj_b;
     cv.Co = D; cv.ksize = 1; cv.pad = 0; cv.out = s.tE; cv.out_bstride = (int64_t)D * T_ac; cv.T_out = T_ac; cv.B = B;
+    if (w.final_proj_w3 && D % 32 == 0 && !getenv("VB_STEM_F32")) { cv.wp = (const bf16_t*)w.final_proj_w3; cv.Ci_pad = D; cv.wp_plane = (int64_t)D * D; }
     VB_TRY(launch_conv1d(cv, st));
     VB_TRY(launch_transpose_bct_btc(s.tE, B, D, T_ac, T, cd.ac, st));
 

@@ -68,7 +68,8 @@ class DiTEngine:
                                 cfg.context_dim, cfg.ori_dim, cfg.max_len, self.np, cfg.norm_eps)
         w = L.DitWeights()
         for name in L.TOP_FIELDS:
-            setattr(w, name, self.packed["top"][name].data_ptr())
+            t = self.packed["top"][name]
+            setattr(w, name, t.data_ptr() if t is not None else None)
         for i, b in enumerate(self.packed["blocks"]):
             for name in L.BLOCK_FIELDS:
                 setattr(w.blocks[i], name, b[name].data_ptr())

@@ -109,6 +109,11 @@ def pack_dit(sd: Dict[str, Tensor], cfg, n_planes: int, device) -> Dict[str, obj
     top["midi_conv_w"], top["midi_conv_b"] = pack_conv(g("midi_proj.0.weight")), g("midi_proj.0.bias")
     top["beats_conv_w"], top["beats_conv_b"] = pack_conv(g("beats_proj.0.weight")), g("beats_proj.0.bias")
     top["final_proj_w"], top["final_proj_b"] = pack_conv(g("final_proj.weight")), g("final_proj.bias")
+    # production (bf16) mode: the once-per-clip stem convolutions (17.7 GFLOP per clip) run on the bf16x3 kernel like every other
+    # convolution of the path; the parity ("split") mode keeps them exact fp32 so the acoustic gate logits - and with them the
+    # bit-identical routing of the golden vectors - do not depend on the split kernel's 3e-5
+    for k in ("midi_conv_w", "beats_conv_w", "final_proj_w"):
+        top[k + "3"] = pack_conv_x3(top[k])[0] if n_planes == 1 else None
     top["c_emb0"], top["c_emb0_b"] = to_planes(g("c_embedder.mlp.0.weight"), 2), g("c_embedder.mlp.0.bias")
     top["c_emb2"], top["c_emb2_b"] = to_planes(g("c_embedder.mlp.2.weight"), 2), g("c_embedder.mlp.2.bias")
     top["c_ln_w"], top["c_ln_b"] = g("c_embedder.mlp.3.weight"), g("c_embedder.mlp.3.bias")
