@@ -12,6 +12,10 @@ here against those fixtures.  The one piece with no reference source in the tree
 is the fixed-step Euler of ``torchdyn.NeuralODE`` (un-pinned dependency, SURVEY
 §8 A4): **parity unpinned** for that solver loop alone - it is restated from its
 published algorithm, x <- x + (t[k+1]-t[k]) * f(t[k], x).
+The mel front-end adds a second such piece: the mel FILTERBANK is
+``librosa.filters.mel`` upstream (librosa==0.10.1, absent here) - restated from its
+published algorithm, **parity unpinned** for ``slaney_mel_filterbank`` alone; the
+rest of ``melnet_forward`` is pinned against the reference's own MelNet.
 
 All citations are relative to /root/reference.
 """
