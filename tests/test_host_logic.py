@@ -271,3 +271,22 @@ def test_reference_import_paths_of_the_mel_front_end():
     assert net.mel_basis.shape == (80, 641) and net.hann_window.shape == (1280,) and net.frames(480000) == 1500 and net.frames(480000, center=True) == 1504
     with pytest.raises(ValueError):
         MelNet(dict(fft_size=1024, audio_num_mel_bins=80, audio_sample_rate=24000, hop_size=300, win_size=1024, fmin=0, fmax=8000))
+
+
+def test_entry_script_keeps_the_reference_cli(monkeypatch):
+    """Every flag of the reference's scripts/test_final.py:34-98 parses here with the same type (defaults differ only where the
+    reference hard-codes paths of its authors' machines)."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("vb_test_final", os.path.join(ROOT, "scripts", "test_final.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["test_final.py", "--config", "c.yaml", "--ckpt", "m.ckpt", "--manifest_path", "t.tsv", "--other_condition",
+                                      "midi.npy", "--ddim_steps", "50", "--n_samples", "2", "--scale", "2.5", "--scales", "1-2-3", "--save_dir", "out",
+                                      "--save_plot", "--num_gpus", "4", "--sample_rate", "24000"])
+    a = mod.parse_args()
+    assert (a.config, a.ckpt, a.manifest_path, a.other_condition) == ("c.yaml", "m.ckpt", "t.tsv", "midi.npy")
+    assert (a.ddim_steps, a.n_samples, a.scale, a.scales, a.save_dir, a.save_plot, a.num_gpus, a.sample_rate) == (50, 2, 2.5, "1-2-3", "out", True, 4, 24000)
+    monkeypatch.setattr(sys, "argv", ["test_final.py"])
+    d = mod.parse_args()
+    assert d.scales == "1-3" and d.scale == 3.0 and d.n_samples == 1 and d.save_dir == "test" and d.num_gpus == 1 and d.sample_rate == 24000
