@@ -36,6 +36,7 @@ struct GemmDev {
     float* out32; int ldc32;
     const float* gate; int gate_ld; int T;
     const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
+    int ncc, rpx;                   // 128x128 kernel, wide N: column tiles are visited in chunks of ncc (0 = off) over the rpx row tiles of an XCD
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
     float rT, rhd, rD;              // reciprocals for fdiv(): the epilogues decompose row -> (clip, t) and column -> (head, d)
@@ -485,8 +486,19 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev 
     {
         const int L = blockIdx.x, nN = p.n_tiles;
         const int jx = L >> 3;
-        tile_n = jx % nN;
-        int tmg = (jx / nN) * 8 + (L & 7);
+        int rt;
+        if (p.ncc > 0) {
+            // wide N (QKV: 18 column tiles = 3.5 MB of weights against a 4 MB L2 per XCD): an XCD walks ALL its row tiles for one
+            // chunk of ncc column tiles before moving to the next chunk, so the live weight set is ncc/nN of the matrix
+            const int per = p.rpx * p.ncc;
+            const int ch = jx / per, rem = jx - ch * per;
+            rt = rem / p.ncc;
+            tile_n = ch * p.ncc + (rem - rt * p.ncc);
+        } else {
+            tile_n = jx % nN;
+            rt = jx / nN;
+        }
+        int tmg = rt * 8 + (L & 7);
         if (p.group_off) {
             bool found = false;
             for (int gi = 0; gi < p.ngroups; ++gi) {
@@ -1111,6 +1123,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
+    d.ncc = 0; d.rpx = (mt + 7) / 8;
+    if (!cfg && !a.group_off) {       // VB_GEMM_NCHUNK=c (tuning, default off until measured in the pipeline): column chunking for wide N
+        const char* ec = getenv("VB_GEMM_NCHUNK");
+        const int c = ec ? atoi(ec) : 0;
+        if (c > 0 && d.n_tiles > c && d.n_tiles % c == 0) d.ncc = c;
+    }
 #define VB_GEMM_CASE(E) \
         case E: \
             if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
