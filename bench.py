@@ -92,7 +92,26 @@ def parse():
     ap.add_argument("--cpu-flow-steps", type=int, default=4)
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--save-out", default=None, help="directory: every rank writes the waveforms of its last pass (clip-indexed .npy)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` on its own: start one process per GPU, like the reference does with
+    mp.spawn(gen_song, nprocs=num_gpus) (scripts/test_final.py:467-477), by re-running this file under
+    torch.distributed.run (rendezvous on 127.0.0.1).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log(f"spawning {args.gpus} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.call(cmd, env=env)
 
 
 def broadcast_state(sds, rank, world, device):
@@ -198,9 +217,15 @@ def main():
     args = parse()
     if args.cpu_baseline_worker:
         return cpu_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s): one process per GPU is the contract"
+    one_device = bool(os.environ.get("VB_BENCH_ONE_DEVICE"))
+    if not one_device:
+        assert torch.cuda.device_count() >= world, f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}"
     if os.environ.get("VB_BENCH_ONE_DEVICE"):          # functional test of the N > 1 code path on a 1-GPU box (gloo, all ranks on cuda:0)
         local = 0
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
@@ -224,9 +249,19 @@ def main():
         sds = [synth.make_state_dict(s, SEED + i) for i, s in enumerate(shapes)]
     else:
         sds = [{k: torch.empty(shp) for k, (shp, _) in s.items()} for s in shapes]
-    sds_cpu = sds
+    bcast_ms, bcast_bytes = None, 0
     if world > 1:
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
         sds = broadcast_state(sds, rank, world, device)
+        torch.cuda.synchronize()
+        bcast_ms = 1e3 * (time.perf_counter() - t0)
+        bcast_bytes = 4 * sum(v.numel() for sd in sds for v in sd.values())
+        seen = torch.ones(1, device=device)
+        dist.all_reduce(seen)                      # every rank reports in over the data-path backend (RCCL unless one-device test)
+        assert int(seen.item()) == world
     log("weights ready; packing")
     ctx = Context(device)
     S = max(1, args.streams)
@@ -343,6 +378,9 @@ def main():
             "value": total_mel_s / elapsed,
             "unit": "mel-s/s",
             "n_gpus": world,
+            "ranks": {"world": world, "backend": ("gloo (VB_BENCH_ONE_DEVICE functional test)" if os.environ.get("VB_BENCH_ONE_DEVICE") else
+                                                 "nccl (RCCL)") if world > 1 else None,
+                      "weight_broadcast_ms": bcast_ms, "weight_broadcast_bytes": bcast_bytes, "collectives_in_timed_region": 0},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -370,8 +408,16 @@ def main():
             log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out))
+    if args.save_out:
+        import numpy as np
+        os.makedirs(args.save_out, exist_ok=True)
+        for w in workers:
+            wav = w["wav"].detach().cpu().numpy()
+            for i in range(wav.shape[0]):
+                np.save(os.path.join(args.save_out, f"clip{w['clip_base'] + i:04d}.npy"), wav[i])
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -53,3 +53,22 @@ def test_broadcast_and_sharding_world2(tmp_path):
     assert all(p["ok"] for p in parts), "weights differ after broadcast"
     assert torch.equal(torch.cat([p["x"] for p in parts]), whole["x_latent"])      # shards == single-process batch, bitwise
     assert torch.equal(torch.cat([p["midi"] for p in parts]), whole["midi"])
+
+
+def test_bench_spawns_its_own_ranks_and_checks_the_world(tmp_path):
+    """`python bench.py --gpus 2` starts two ranks itself (torch.distributed.run on 127.0.0.1, as the reference's
+    mp.spawn(gen_song, nprocs=num_gpus) does, scripts/test_final.py:467-477): each rank reaches main() with WORLD_SIZE=2 and
+    stops - loudly - at the GPU requirement on this CPU-only box; and --gpus N under a launcher that started a different
+    number of ranks is an error, not a silent 1-GPU measurement."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True,
+                           text=True, timeout=300, env=env)
+        assert r.returncode != 0
+        assert "spawning 2 ranks" in r.stderr
+        assert r.stderr.count("--gpus 2 needs 2 visible GPUs") >= 2 or r.stderr.count("no GPU visible") >= 2, r.stderr[-2000:]
+    env.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode != 0 and "one process per GPU" in r.stderr

@@ -1,0 +1,42 @@
+"""BASELINE configs[3] (batch-shard over ranks) exercised on ONE GPU: `python bench.py --gpus 2` spawns its own two ranks
+(VB_BENCH_ONE_DEVICE: both on cuda:0, gloo instead of RCCL for the weight broadcast), every rank generates its own clips,
+and each clip must equal - bitwise - the clip a single process generates for the same global clip index: noise streams and
+inputs are keyed by the global clip index, so the result is independent of world size (the reference shards the
+same way with DistributedSampler, scripts/test_final.py:351-357,467-477)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_two_ranks_one_command_match_single_process(tmp_path):
+    common = ["--steps", "1", "--warmup", "1", "--flow-steps", "3", "--streams", "1", "--no-cpu-baseline"]
+    d2, d1 = str(tmp_path / "w2"), str(tmp_path / "w1")
+    out2 = _bench(["--gpus", "2", "--batch", "2", "--save-out", d2] + common, {"VB_BENCH_ONE_DEVICE": "1"})
+    assert out2["n_gpus"] == 2 and out2["ranks"]["world"] == 2 and out2["ranks"]["weight_broadcast_bytes"] > 5e8
+    assert out2["scaling"] == "weak" and out2["config"]["clips_per_gpu"] == 2
+    out1 = _bench(["--gpus", "1", "--batch", "4", "--save-out", d1] + common, {})
+    assert out1["n_gpus"] == 1
+    names = sorted(os.listdir(d1))
+    assert names == sorted(os.listdir(d2)) == [f"clip{i:04d}.npy" for i in range(4)]
+    for n in names:
+        a, b = np.load(os.path.join(d1, n)), np.load(os.path.join(d2, n))
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert np.array_equal(a, b), f"{n}: rank-sharded output differs from the single-process output (max |d| = {np.abs(a - b).max():.3e})"

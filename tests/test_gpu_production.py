@@ -1,0 +1,107 @@
+"""Parity of the BENCHMARKED configuration (BASELINE configs[1]): bf16 production precision, full 20 s geometry
+(T = 752, L = 80), many CFG Euler steps, against the pinned CPU oracle at north_star's tolerances - latent relative
+error <= 1e-3 and mel L1 < 1e-3 - with the routing flip count of every block reported per step.
+
+Reference semantics under test: flag_large_dit_moe.py:353-386 (fp32 attention path), vocal2music_moe.py:81-93,150-151
+(hard Gumbel routing), cfm1_audio.py:154-162 (CFG), cfm1_audio_sampler.py:107-116 (Euler loop)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from tests.helpers import SEED, clip_batch, describe, exp_noise, gumbel_arrays, gumbel_arrays_steps, rel_l2
+from versband_amd import model as vm
+from versband_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LATENT_TOL = 1e-3      # north_star: "within 1e-3 relative mel-latent error"
+MEL_L1_TOL = 1e-3      # north_star: "mel L1 vs reference < 1e-3"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from versband_amd.engine import Context
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return Context("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def prod(ctx):
+    """bf16 production engine + VAE decoder on the synthetic checkpoints bench.py uses."""
+    from versband_amd.engine import DiTEngine, build_vae_decoder
+    dcfg = synth.DiTConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), SEED + 1)
+    return dict(sd=sd, sdv=sdv, eng=DiTEngine(ctx, dcfg, sd, precision="bf16"), vae=build_vae_decoder(ctx, sdv))
+
+
+def _oracle_trajectory(sd, inp, scale, steps, noise_steps):
+    """ref_cpu.sample_cfg unrolled so that every state x_k and every evaluation's routing indices are kept."""
+    T = inp["x_latent"].shape[-1]
+    cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
+    cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], inp["midi"], inp["beats"], T)
+    t_span, idx = ref_cpu.t_index_table(steps + 1)
+    x = inp["x_latent"].clone()
+    B = x.shape[0]
+    states, routes = [x.clone()], []
+    t = t_span[0]
+    for k in range(steps):
+        dt = t_span[k + 1] - t                     # torchdyn's fixed-step bookkeeping, as ref_cpu.sample_cfg restates it
+        ti = torch.full((B,), int(idx[k]), dtype=torch.long)
+        e_c, aux_c = ref_cpu.dit_forward(sd, x, ti, cc, noise_steps[k][0], return_aux=True)
+        e_u, aux_u = ref_cpu.dit_forward(sd, x, ti, cu, noise_steps[k][1], return_aux=True)
+        x = x + dt * (e_u + scale * (e_c - e_u))
+        t = t + dt
+        states.append(x.clone())
+        routes.append((aux_c, aux_u))
+    return states, routes, [int(v) for v in idx[:steps]]
+
+
+def _flip_report(eng, cond, states, routes, idx, noise_steps, B, T, depth=4):
+    """teacher-forced: the HIP engine evaluates the ORACLE's state x_k, so a differing routing index is a flip caused by
+    the arithmetic of this evaluation alone (not by an earlier divergence).  -> flips[k][block] over both gates, both branches."""
+    N = B * T
+    out = np.zeros((len(idx), depth), dtype=np.int64)
+    for k, ti in enumerate(idx):
+        t_idx = torch.full((2 * B,), ti, dtype=torch.long)
+        _, r = eng.forward(states[k], t_idx, cond, noise=gumbel_arrays(noise_steps[k]), return_routes=True)
+        r = r.cpu().long()
+        for br in (0, 1):
+            aux = routes[k][br]
+            for i in range(depth):
+                out[k, i] += int((r[i, 0, br * N:(br + 1) * N] != aux[f"ic{i}"]).sum())
+                out[k, i] += int((r[i, 1, br * N:(br + 1) * N] != aux[f"ia{i}"]).sum())
+    return out
+
+
+@pytest.mark.parametrize("B,steps", [(2, 10), (1, 50)])
+def test_c2_bf16_production_vs_oracle(prod, B, steps):
+    """configs[1]'s precision and geometry: bf16 DiT, T = 752, L = 80, CFG scale 3, injected router noise identical to the
+    oracle's; 10 steps at B = 2, then the full 50-step schedule for one clip."""
+    T, Lc, E, scale = 752, 80, 4, 3.0
+    eng, vae, sd, sdv = prod["eng"], prod["vae"], prod["sd"], prod["sdv"]
+    inp = clip_batch(B, T, Lc)
+    noise_steps = [[exp_noise(B, T, E, 2 * k + br, 4) for br in (0, 1)] for k in range(steps)]
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    idx, dts = vm.euler_tables(steps + 1)
+    z, traj = eng.sample_cfg(inp["x_latent"], cond, idx, dts, scale, noise=gumbel_arrays_steps(noise_steps), return_traj=True)
+    mel = vae.run(z)
+    torch.cuda.synchronize()
+    states, routes, idx_ref = _oracle_trajectory(sd, inp, scale, steps, noise_steps)
+    assert list(idx) == idx_ref
+    z_ref = states[-1]
+    mel_ref = ref_cpu.vae_decode(sdv, z_ref)
+    flips = _flip_report(eng, cond, states, routes, idx_ref, noise_steps, B, T)
+    per_step = [rel_l2(traj[k + 1], states[k + 1]) for k in range(steps)]
+    decisions = 2 * 2 * B * T                      # per block and evaluation pair: 2 gates x 2 branches x tokens
+    print(f"\n[bf16 production, B={B}, {steps} steps] latent rel_l2 = {rel_l2(z, z_ref):.3e}; "
+          f"mel L1 = {float((mel.cpu() - mel_ref).abs().mean()):.3e}")
+    print("  per-step latent rel_l2: " + " ".join(f"{e:.1e}" for e in per_step))
+    print(f"  routing flips per block (teacher-forced, summed over steps, of {decisions * steps} decisions each): "
+          f"{flips.sum(0).tolist()}; worst step {int(flips.sum(1).max())}")
+    assert torch.isfinite(z).all()
+    assert rel_l2(z, z_ref) <= LATENT_TOL, describe(f"bf16 {steps}-step latent vs oracle", z, z_ref)
+    assert float((mel.cpu() - mel_ref).abs().mean()) < MEL_L1_TOL, describe("bf16 mel vs oracle", mel, mel_ref)
+    # hard routing: flips can only come from near-ties of the two best gate values; they must stay a vanishing fraction
+    assert flips.sum() <= 2e-3 * decisions * steps * 4, f"routing flip rate too high: {flips.sum(0).tolist()}"
