@@ -2,11 +2,16 @@
 """Headline benchmark: mel-seconds generated per second (BASELINE.json metric).
 
 A "step" = one pass of the whole hot path over one batch of synthetic clips that are already
-resident in HBM: conditioning precompute -> 50 Euler flow steps with CFG (2 network evaluations
-per step, batched) -> VAE decode -> full HiFi-GAN decode.  Workload = BASELINE.json configs[1]:
-batch 8 x 20 s clips, bf16 DiT + fp32 VAE/vocoder, random-init checkpoints of the configured
-architecture (synthetic, no network).  N>1: one process per GPU, clips sharded by rank (weak
-scaling), weights broadcast once from rank 0 over RCCL, no data-path collective.
+resident in HBM: conditioning precompute -> Euler flow steps with CFG (2 network evaluations
+per step, batched) -> VAE decode -> full HiFi-GAN decode.
+
+  --workload c2 (default)  BASELINE configs[1]: batch 8 x 20 s clips, 50 flow steps, bf16 DiT + fp32-class VAE/vocoder
+  --workload c3            BASELINE configs[2]: Band-MoE stress, num_experts = 8, batch 32 (48 128 token rows per CFG branch)
+  --workload c5            BASELINE configs[4]: long-form, batch 4 x 120 s (T = 4500 latent frames in windows of 1500 tokens,
+                           cross-faded) + VAE decode of the whole latent + halo'd chunked vocoding
+
+N > 1: one process per GPU (`python bench.py --gpus N` spawns them itself; under torch.distributed.run it joins the ranks it
+is given), clips sharded by rank (weak scaling), weights broadcast once from rank 0 over RCCL, no data-path collective.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
 """
@@ -25,13 +30,18 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-CLIP_SECONDS = 20.0
-T_LAT, L_CTX = 752, 80
+L_CTX = 80
 SEED = 1234
-PEAK = {0: ("mfma", 2500.0, "bf16 MFMA GEMM (DiT projections + experts)"),
-        1: ("mfma", 2500.0, "bf16 flash attention"),
-        2: ("mfma", 2500.0 / 3.0, "split-bf16 (bf16x3) MFMA implicit-GEMM conv1d (VAE + HiFi-GAN); peak = bf16 dense / 3 passes")}
-
+HBM_PEAK_TBS = 8.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s float4-copy rate measured)
+MFMA_BF16_TF = 2500.0       # dense bf16 MFMA peak
+# kernel classes of the library's HIP-event profiler (csrc/kernels.h): name, binding roof, peak TFLOP/s
+CLASSES = {
+    0: ("bf16 MFMA GEMM (DiT projections, routed + band experts)", "mfma", MFMA_BF16_TF),
+    1: ("bf16 flash attention (self + T5 cross)", "mfma", MFMA_BF16_TF),
+    2: ("split-bf16 (bf16x3) MFMA implicit-GEMM conv1d (VAE + HiFi-GAN)", "mfma", MFMA_BF16_TF / 3.0),
+    3: ("fused HiFi-GAN ResBlock pair (bf16x3 MFMA, intermediate in LDS)", "mfma|hbm", MFMA_BF16_TF / 3.0),
+}
+CLASS_KERNELS = {0: ("gemm_bf16", "band_ffn", "moe_ffn"), 1: ("attn_kernel",), 2: ("conv1d_",), 3: ("respair_",)}
 
 _T0 = time.time()
 
@@ -53,16 +63,16 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-CLASS_KERNELS = {0: ("gemm_bf16",), 1: ("attn_kernel",), 2: ("conv1d_", "respair_")}
-
-
 def pmc_traffic(cls):
-    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json:
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; counter unit = KB; FETCH_SIZE doubled for
-    gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch of a kernel class from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_summary.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command; counter unit = KB; FETCH_SIZE doubled for gfx950 as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside the timed process, so this figure
+    comes from a FILE and the JSON line says so.  (None, None) when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    path = files[-1]
     try:
         d = json.load(open(path))
         tot, n = 0.0, 0
@@ -73,9 +83,9 @@ def pmc_traffic(cls):
         for name, v in d.get("WRITE_SIZE", {}).items():
             if any(k in name for k in CLASS_KERNELS[cls]):
                 tot += v["sum_kb"] * 1024.0
-        return (tot / n) if n else None
+        return ((tot / n) if n else None), os.path.relpath(path, ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def parse():
@@ -83,17 +93,28 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 8 / 32 / 4 for c2 / c3 / c5)")
+    ap.add_argument("--experts", type=int, default=None, help="Band-MoE experts per group (default 4; 8 for c3)")
+    ap.add_argument("--seconds", type=float, default=None, help="clip length in seconds (default 20; 120 for c5)")
     ap.add_argument("--flow-steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
     ap.add_argument("--scale", type=float, default=3.0)
-    ap.add_argument("--streams", type=int, default=2, help="independent sub-batches per GPU, one HIP stream + host thread each")
+    ap.add_argument("--streams", type=int, default=None, help="independent sub-batches per GPU, one HIP stream + host thread each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the untimed one-stream pass that measures every kernel class alone")
+    ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--cpu-flow-steps", type=int, default=4)
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--save-out", default=None, help="directory: every rank writes the waveforms of its last pass (clip-indexed .npy)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    dflt = {"c2": (8, 4, 20.0, 2), "c3": (32, 8, 20.0, 2), "c5": (4, 4, 120.0, 1)}[a.workload]
+    a.batch = dflt[0] if a.batch is None else a.batch
+    a.experts = dflt[1] if a.experts is None else a.experts
+    a.seconds = dflt[2] if a.seconds is None else a.seconds
+    a.streams = dflt[3] if a.streams is None else a.streams
+    return a
 
 
 def spawn_ranks(args):
@@ -134,36 +155,35 @@ def broadcast_state(sds, rank, world, device):
     return out
 
 
-def cpu_baseline(sd_d, sd_v, sd_h, hp, flow_steps_total, cpu_steps, scale):
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sd_d, sd_v, sd_h, hp, flow_steps_total, cpu_steps, scale, T_lat=752, clip_seconds=20.0):
     """The CPU oracle (a port of the reference's algorithm, routed + hoisted variant) on the host cores:
     B=1, one 20 s clip; `cpu_steps` Euler steps are timed and extrapolated linearly to the full count,
     VAE decode and HiFi-GAN are timed in full."""
     from oracle import ref_cpu
     from tests.helpers import clip_batch, exp_noise
-    from versband_amd import model as vm
     cores = usable_cores()
     torch.set_num_threads(cores)
-    inp = clip_batch(1, T_LAT, L_CTX, clip0=0, seed=SEED)
+    inp = clip_batch(1, T_lat, L_CTX, clip0=0, seed=SEED)
     t0 = time.perf_counter()
-    cc = ref_cpu.dit_precompute(sd_d, inp["t5_cond"], inp["midi"], inp["beats"], T_LAT)
-    cu = ref_cpu.dit_precompute(sd_d, inp["t5_uncond"], inp["midi"], inp["beats"], T_LAT)
+    cc = ref_cpu.dit_precompute(sd_d, inp["t5_cond"], inp["midi"], inp["beats"], T_lat)
+    cu = ref_cpu.dit_precompute(sd_d, inp["t5_uncond"], inp["midi"], inp["beats"], T_lat)
     t_pre = time.perf_counter() - t0
-    noise = {(k, br): exp_noise(1, T_LAT, 4, 2 * k + br, 4, seed=SEED) for k in range(cpu_steps) for br in (0, 1)}
+    noise = {(k, br): exp_noise(1, T_lat, 4, 2 * k + br, 4, seed=SEED) for k in range(cpu_steps) for br in (0, 1)}
     t0 = time.perf_counter()
-    z = ref_cpu.sample_cfg(sd_d, inp["x_latent"], cc, cu, scale, flow_steps_total + 1,
-                           lambda k, br: noise[(k, br)]) if cpu_steps >= flow_steps_total else None
-    if z is None:      # bounded sample: run cpu_steps Euler steps of the same schedule
-        t_span, idx = ref_cpu.t_index_table(flow_steps_total + 1)
-        x = inp["x_latent"].clone()
-        for k in range(cpu_steps):
-            ti = torch.full((1,), idx[k], dtype=torch.long)
-            e_c = ref_cpu.dit_forward(sd_d, x, ti, cc, noise[(k, 0)])
-            e_u = ref_cpu.dit_forward(sd_d, x, ti, cu, noise[(k, 1)])
-            x = x + (t_span[k + 1] - t_span[k]) * (e_u + scale * (e_c - e_u))
-        z = x
-    t_flow = (time.perf_counter() - t0) * (flow_steps_total / float(min(cpu_steps, flow_steps_total)))
+    t_span, idx = ref_cpu.t_index_table(flow_steps_total + 1)
+    x = inp["x_latent"].clone()
+    n_run = min(cpu_steps, flow_steps_total)
+    for k in range(n_run):       # bounded sample: the first n_run Euler steps of the same schedule
+        ti = torch.full((1,), idx[k], dtype=torch.long)
+        e_c = ref_cpu.dit_forward(sd_d, x, ti, cc, noise[(k, 0)])
+        e_u = ref_cpu.dit_forward(sd_d, x, ti, cu, noise[(k, 1)])
+        x = x + (t_span[k + 1] - t_span[k]) * (e_u + scale * (e_c - e_u))
+    t_flow = (time.perf_counter() - t0) * (flow_steps_total / float(n_run))
     t0 = time.perf_counter()
-    mel = ref_cpu.vae_decode(sd_v, z)
+    mel = ref_cpu.vae_decode(sd_v, x)
     t_vae = time.perf_counter() - t0
     t0 = time.perf_counter()
     ref_cpu.hifigan_forward(sd_h, hp, mel)
@@ -174,14 +194,14 @@ def cpu_baseline(sd_d, sd_v, sd_h, hp, flow_steps_total, cpu_steps, scale):
     t0 = time.perf_counter()
     ti = torch.full((1,), 0, dtype=torch.long)
     for br, t5 in ((0, inp["t5_cond"]), (1, inp["t5_uncond"])):
-        cnd = ref_cpu.dit_precompute(sd_d, t5, inp["midi"], inp["beats"], T_LAT)
+        cnd = ref_cpu.dit_precompute(sd_d, t5, inp["midi"], inp["beats"], T_lat)
         ref_cpu.dit_forward(sd_d, inp["x_latent"], ti, cnd, noise[(0, br)], dense=True)
     t_dense = (time.perf_counter() - t0) * flow_steps_total
-    dense = {"value": CLIP_SECONDS / (t_dense + t_vae + t_voc), "unit": "mel-s/s",
+    dense = {"value": clip_seconds / (t_dense + t_vae + t_voc), "unit": "mel-s/s",
              "what": f"reference-faithful evaluation order: dense experts + conditioning recomputed per evaluation, 1 of {flow_steps_total} "
                      f"steps timed and scaled to {t_dense:.1f}s, same VAE / HiFi-GAN times"}
-    return {"value": CLIP_SECONDS / total, "unit": "mel-s/s", "cores": cores, "kind": "port", "reference_faithful": dense,
-            "sample": f"B=1 x 20 s clip on {cores} threads: cond precompute {t_pre:.2f}s + {min(cpu_steps, flow_steps_total)} of "
+    return {"value": clip_seconds / total, "unit": "mel-s/s", "cores": cores, "kind": "port", "reference_faithful": dense,
+            "sample": f"B=1 x 20 s clip on {cores} threads: cond precompute {t_pre:.2f}s + {n_run} of "
                       f"{flow_steps_total} CFG Euler steps timed and scaled to {t_flow:.1f}s + full VAE decode {t_vae:.2f}s + "
                       f"full HiFi-GAN {t_voc:.2f}s (torch fp32 oracle, routed experts, conditioning hoisted)"}
 
@@ -213,6 +233,27 @@ def cpu_worker(args):
     print(json.dumps(cpu_baseline(sds[0], sds[1], sds[2], hcfg.as_hparams(), args.flow_steps, args.cpu_flow_steps, args.scale)))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+def parity_check(z0, mel0):
+    """clip 0 of the first timed pass (bf16 production precision, router noise drawn on the device) against the oracle's replay of
+    exactly that clip (tests/golden/bench_clip0.npz, written by oracle/gen_bench_digest.py from the CPU oracle + the host
+    restatement of the device noise stream): north_star's tolerances, latent rel-L2 <= 1e-3 and mel L1 < 1e-3."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "bench_clip0.npz")
+    if not os.path.exists(path):
+        return {"ok": None, "why": "tests/golden/bench_clip0.npz missing"}
+    g = np.load(path)
+    z_ref = torch.from_numpy(g["z"]).double()
+    z = z0.detach().double().cpu()
+    rel = float((z - z_ref).norm() / z_ref.norm())
+    m = mel0.detach().double().cpu().reshape(-1)
+    idx = torch.from_numpy(g["mel_idx"])
+    l1 = float((m[idx] - torch.from_numpy(g["mel_val"])).abs().mean())
+    l2 = abs(float(m.norm()) - float(g["mel_l2"][0])) / float(g["mel_l2"][0])
+    return {"ok": bool(rel <= 1e-3 and l1 < 1e-3 and l2 <= 1e-3), "latent_rel_l2": rel, "mel_l1_sampled": l1, "mel_l2_rel": l2, "tol": 1e-3,
+            "against": "tests/golden/bench_clip0.npz (CPU oracle replay of clip 0, pass 0: same seed, same device-keyed router noise)"}
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
@@ -223,27 +264,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} rank(s): one process per GPU is the contract"
-    one_device = bool(os.environ.get("VB_BENCH_ONE_DEVICE"))
-    if not one_device:
-        assert torch.cuda.device_count() >= world, f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}"
-    if os.environ.get("VB_BENCH_ONE_DEVICE"):          # functional test of the N > 1 code path on a 1-GPU box (gloo, all ranks on cuda:0)
+    one_device = bool(os.environ.get("VB_BENCH_ONE_DEVICE"))       # functional test of the N > 1 code path on a 1-GPU box (gloo, all ranks on cuda:0)
+    if one_device:
         local = 0
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
+    if not one_device:
+        assert torch.cuda.device_count() >= world, f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}"
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
-        if os.environ.get("VB_BENCH_ONE_DEVICE"):
+        if one_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
     from tests.helpers import clip_batch
     from versband_amd import _lib as L
+    from versband_amd import longform
     from versband_amd import model as vm
     from versband_amd import synth
     from versband_amd.engine import Context, DiTEngine, build_hifigan, build_vae_decoder
 
-    dcfg, vcfg, hcfg = synth.DiTConfig(), synth.VAEConfig(), synth.HifiGanConfig()
+    long = args.workload == "c5"
+    T_mel = int(round(args.seconds * 75.0))
+    T_mel = (T_mel + 7) // 8 * 8                      # unit_frames_multiple (scripts/test_final.py:213,319)
+    T_lat = T_mel // 2
+    clip_seconds = T_mel / 75.0 if long else args.seconds
+    dcfg, vcfg, hcfg = synth.DiTConfig(num_experts=args.experts), synth.VAEConfig(), synth.HifiGanConfig()
+    if not long:
+        assert T_lat <= dcfg.max_len, f"{args.seconds} s = {T_lat} latent frames exceeds max_len {dcfg.max_len}: use --workload c5"
     shapes = [synth.dit_shapes(dcfg), synth.vae_decoder_shapes(vcfg), synth.hifigan_shapes(hcfg)]
     if rank == 0:
         sds = [synth.make_state_dict(s, SEED + i) for i, s in enumerate(shapes)]
@@ -269,26 +318,40 @@ def main():
     assert B % S == 0, "--batch must be divisible by --streams"
     Bs = B // S
     idx, dts = vm.euler_tables(args.flow_steps + 1)
-    # S independent sub-batches, each with its own engine handles, on its own HIP stream driven by its own host thread:
-    # kernels of different sub-batches overlap on the GPU and fill each other's tile-quantisation tails.
+
+    def make_worker(nclips, clip_base, share=None):
+        eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision, share=share)
+        inp = clip_batch(nclips, T_lat, L_CTX, clip0=clip_base, seed=SEED)
+        return dict(eng=eng, vae=build_vae_decoder(ctx, sds[1]), voc=build_hifigan(ctx, sds[2], hcfg.as_hparams()),
+                    x0=inp["x_latent"].to(device), t5c=inp["t5_cond"].to(device), t5u=inp["t5_uncond"].to(device),
+                    t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
+                    beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=clip_base, wav=None, z0=None, mel0=None)
+
+    # S independent sub-batches, each with its own engine handle (shared packed weights), on its own HIP stream driven by its own
+    # host thread: kernels of different sub-batches overlap on the GPU and fill each other's tile-quantisation tails.
     workers = []
     for si in range(S):
-        eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision)
-        vae = build_vae_decoder(ctx, sds[1])
-        voc = build_hifigan(ctx, sds[2], hcfg.as_hparams())
-        inp = clip_batch(Bs, T_LAT, L_CTX, clip0=rank * B + si * Bs, seed=SEED)
-        workers.append(dict(eng=eng, vae=vae, voc=voc, x0=inp["x_latent"].to(device),
-                            t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
-                            beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=rank * B + si * Bs,
-                            wav=None))
+        workers.append(make_worker(Bs, rank * B + si * Bs, share=workers[0]["eng"] if workers else None))
+
+    def one_pass(w, k):
+        if long:
+            z = longform.sample_long(w["eng"], w["x0"], w["t5c"], w["t5u"], w["midi"], w["beats"], idx, dts, args.scale,
+                                     window=dcfg.max_len, overlap=128, seed=SEED + k, clip_base=w["clip_base"])
+            mel = w["vae"].run(z)
+            w["wav"] = longform.vocode_chunked(w["voc"], mel, chunk=3000, halo=32)
+        else:
+            cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_lat)
+            z = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + k, clip_base=w["clip_base"])
+            mel = w["vae"].run(z)
+            w["wav"] = w["voc"].run(mel)
+        if k == 0:
+            w["z0"], w["mel0"] = z[:1], mel[:1]
 
     def run_worker(w, ks):
         torch.cuda.set_device(device)           # a new host thread starts on device 0: bind it to this rank's GPU
         with torch.cuda.stream(w["stream"]):
             for k in ks:
-                cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_LAT)
-                z = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + k, clip_base=w["clip_base"])
-                w["wav"] = w["voc"].run(w["vae"].run(z))
+                one_pass(w, k)
 
     def run_passes(ks):
         import threading
@@ -310,50 +373,49 @@ def main():
 
     lib = L.load()
     torch.cuda.synchronize()
-    log(f"engines built ({S} stream(s) x {Bs} clips); warmup")
+    log(f"engines built ({S} stream(s) x {Bs} clips of {clip_seconds:.1f} s, E={args.experts}); warmup")
 
     def read_prof(cls):
-        ms, fl, n, nt = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
-        L.check(lib.vb_prof_read(cls, C.byref(ms), C.byref(fl), C.byref(n), C.byref(nt)), "vb_prof_read")
-        return ms.value, fl.value, n.value, nt.value
+        ms, fl, by, n, nt = C.c_double(), C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
+        L.check(lib.vb_prof_read(cls, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n), C.byref(nt)), "vb_prof_read")
+        return ms.value, fl.value, by.value, n.value, nt.value
 
-    # warmup; the last warmup pass times (a sample of) every kernel class to find the dominant one
-    EVERY = 5            # coprime with the 4 GEMMs / block so the sample walks over every kernel of the class
-    dominant, breakdown = 0, {}
     for wi in range(max(args.warmup, 1)):
-        last = wi == max(args.warmup, 1) - 1
-        if last:
-            L.check(lib.vb_prof_enable(7 | (EVERY << 8)), "prof")
         run_passes([-1 - wi])
         torch.cuda.synchronize()
-        if last:
-            for cls in (0, 1, 2):
-                ms, fl, n, nt = read_prof(cls)
-                breakdown[cls] = ms * (n / nt) if nt else 0.0      # sampled launches extrapolated to the class
-            dominant = max(breakdown, key=breakdown.get)
     assert all(torch.isfinite(w["wav"]).all() for w in workers)
-    # the dominant class alone on the GPU (one stream, the whole batch of B clips): the kernel-quality figure that the
-    # concurrent timed region dilutes (two sub-batches share the CUs, so each launch is slower but two are in flight)
-    isolated = None
-    if S > 1:
-        inp = clip_batch(B, T_LAT, L_CTX, clip0=rank * B, seed=SEED)
-        w = dict(eng=DiTEngine(ctx, dcfg, sds[0], precision=args.precision), vae=build_vae_decoder(ctx, sds[1]),
-                 voc=build_hifigan(ctx, sds[2], hcfg.as_hparams()), x0=inp["x_latent"].to(device),
-                 t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
-                 beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=rank * B, wav=None)
+
+    # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every 5th launch of each class bracketed by
+    # HIP events on the launch stream.  This is the kernel-quality figure (roofline.frac): in the timed region below two
+    # sub-batches share the CUs, so a launch's event-bracketed duration includes the other stream's kernels.
+    EVERY = 5            # coprime with the launches per block, so the sample walks over every kernel of a class
+    table, dominant = [], 0
+    if not args.no_isolated:
+        w = workers[0] if S == 1 else make_worker(B, rank * B, share=workers[0]["eng"])
         run_worker(w, [-100])
         torch.cuda.synchronize()
-        L.check(lib.vb_prof_enable((1 << dominant) | (EVERY << 8)), "prof")
+        L.check(lib.vb_prof_enable(0xF | (EVERY << 8)), "prof")
         run_worker(w, [-101])
         torch.cuda.synchronize()
-        ms, fl, n, nt = read_prof(dominant)
-        if ms > 0 and nt > 0:
-            isolated = {"achieved": fl / (ms * 1e-3) / 1e12, "avg_launch_us": 1e3 * ms / nt, "timed_launches": nt,
-                        "what": f"same class, one stream, one batch of {B} clips (nothing else on the GPU)"}
-        del w
-        torch.cuda.empty_cache()
-    L.check(lib.vb_prof_enable((1 << dominant) | (EVERY << 8)), "prof")
-    log(f"warmup done; class ms/pass = {breakdown}; timing {args.steps} step(s)")
+        per = {}
+        for cls in CLASSES:
+            ms, fl, by, n, nt = read_prof(cls)
+            per[cls] = (ms, fl, by, n, nt)
+            if nt == 0:
+                continue
+            name, bound, peak = CLASSES[cls]
+            tf, tbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e12
+            table.append({"class": name, "bound": bound, "launches_per_pass": n, "timed_launches": nt, "avg_launch_us": 1e3 * ms / nt,
+                          "ms_per_pass": ms * n / nt, "algorithmic_gflop_per_launch": fl / nt / 1e9, "algorithmic_mb_per_launch": by / nt / 1e6,
+                          "tflops": tf, "frac_of_mfma_peak": tf / peak, "mfma_peak_tflops": peak, "algorithmic_tb_per_s": tbs,
+                          "frac_of_hbm_peak": tbs / HBM_PEAK_TBS})
+        L.check(lib.vb_prof_enable(0), "prof")
+        dominant = max(per, key=lambda c: per[c][0] * (per[c][3] / per[c][4]) if per[c][4] else 0.0)
+        if S > 1:
+            del w
+            torch.cuda.empty_cache()
+    L.check(lib.vb_prof_enable((1 << dominant) | (8 << 8)), "prof")
+    log(f"warmup done; dominant class = {CLASSES[dominant][0]}; timing {args.steps} step(s)")
 
     barrier()
     t0 = time.perf_counter()
@@ -366,20 +428,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     log(f"timed region: {elapsed:.3f}s")
-    ms, fl, n, nt = read_prof(dominant)
+    ms, fl, by, n, nt = read_prof(dominant)
     L.check(lib.vb_prof_enable(0), "prof")
 
+    parity = None
+    if rank == 0 and not args.no_parity_check and args.workload == "c2" and args.flow_steps == 50 and args.scale == 3.0 \
+            and args.precision == "bf16" and abs(args.seconds - 20.0) < 1e-9 and args.steps >= 1:
+        parity = parity_check(workers[0]["z0"], workers[0]["mel0"])
+        log(f"parity vs oracle digest: {parity}")
+
     if rank == 0:
-        bound, peak, kname = PEAK[dominant]
-        achieved = (fl / (ms * 1e-3) / 1e12) if (ms > 0 and nt > 0) else 0.0      # flops and time of the timed launches
-        total_mel_s = world * B * CLIP_SECONDS * args.steps
+        name, bound, peak = CLASSES[dominant]
+        conc = (fl / (ms * 1e-3) / 1e12) if (ms > 0 and nt > 0) else 0.0      # flops and time of the timed launches
+        iso = next((r for r in table if r["class"] == name), None)
+        achieved = iso["tflops"] if iso else conc
+        traffic, traffic_file = pmc_traffic(dominant)
+        total_mel_s = world * B * clip_seconds * args.steps
+        wl = {"c2": f"{B} x {clip_seconds:.0f} s clips per GPU (T_lat={T_lat}, T_mel={T_mel}, 24 kHz)",
+              "c3": f"Band-MoE stress: {B} x {clip_seconds:.0f} s clips per GPU, num_experts={args.experts} ({2 * B * T_lat} token rows per evaluation)",
+              "c5": f"long-form: {B} x {clip_seconds:.0f} s clips per GPU (T_lat={T_lat} in windows of {dcfg.max_len} tokens, overlap 128, "
+                    f"cross-faded; VAE on the whole latent; vocoder in 3000-frame chunks with 32-frame halos)"}[args.workload]
         out = {
-            "metric": "mel-seconds generated/sec (20 s clip, %d flow steps)" % args.flow_steps,
+            "metric": "mel-seconds generated/sec (%d s clip, %d flow steps)" % (round(clip_seconds), args.flow_steps),
             "value": total_mel_s / elapsed,
             "unit": "mel-s/s",
             "n_gpus": world,
-            "ranks": {"world": world, "backend": ("gloo (VB_BENCH_ONE_DEVICE functional test)" if os.environ.get("VB_BENCH_ONE_DEVICE") else
-                                                 "nccl (RCCL)") if world > 1 else None,
+            "ranks": {"world": world, "backend": ("gloo (VB_BENCH_ONE_DEVICE functional test)" if one_device else "nccl (RCCL)") if world > 1 else None,
                       "weight_broadcast_ms": bcast_ms, "weight_broadcast_bytes": bcast_bytes, "collectives_in_timed_region": 0},
             "steps": args.steps,
             "warmup": args.warmup,
@@ -390,24 +464,34 @@ def main():
             "dtype": ("bf16 DiT (fp32 accumulate)" if args.precision == "bf16" else "bf16x3 split DiT") +
                      " + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32",
             "data": "synthetic (seeded PRNG clips, random-init checkpoints of the configured architecture)",
-            "config": {"workload": f"{B} x 20 s clips per GPU (T_lat=752, T_mel=1504, 24 kHz), {args.flow_steps} Euler steps x 2 NFE (CFG "
-                                   f"scale {args.scale}), Band-MoE E=4, VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml",
-                       "clips_per_gpu": B, "flow_steps": args.flow_steps, "precision": args.precision,
+            "config": {"workload": wl + f", {args.flow_steps} Euler steps x 2 NFE (CFG scale {args.scale}), Band-MoE E={args.experts}, "
+                                        "VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml",
+                       "baseline_config": {"c2": "configs[1]", "c3": "configs[2]", "c5": "configs[4]"}[args.workload],
+                       "clips_per_gpu": B, "clip_seconds": clip_seconds, "flow_steps": args.flow_steps, "precision": args.precision, "experts": args.experts,
                        "streams_per_gpu": S, "parallelism": f"batch-shard x{world} ({S} concurrent sub-batches of {Bs} clips per GPU)"},
-            "roofline": {"bound": bound, "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": pmc_traffic(dominant),
-                         "traffic_note": "HBM bytes per launch averaged over the class, from the committed rocprofv3 --pmc FETCH_SIZE / "
-                                         "WRITE_SIZE passes of this command (profiles/r01_pmc_summary.json); algorithmic bytes in DESIGN.md",
-                         "avg_launch_us": (1e3 * ms / nt) if nt else None, "launches_per_step": n / max(args.steps, 1),
-                         "timed_launches": nt, "note": "every 5th launch of the class is bracketed by HIP events on its own stream; with "
-                         "streams_per_gpu > 1 a launch shares the GPU with the other sub-batch's kernels, so its duration includes that overlap",
-                         "isolated": (dict(isolated, frac=isolated["achieved"] / peak) if isolated else None),
-                         "class_ms_per_step_warmup": {PEAK[c][2]: round(v, 3) for c, v in breakdown.items()}},
+            "parity_check": parity,
+            "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "how": ("dominant class = largest GPU time per pass; achieved = algorithmic flops of its event-timed launches / their "
+                                 "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 5th "
+                                 "launch bracketed by HIP events on the launch stream)") if iso else "timed-region launches (no isolated pass)",
+                         "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
+                         "traffic": traffic,
+                         "traffic_source": (f"file: {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per "
+                                            "the gfx950 note; PMC cannot be read in-process)") if traffic else None,
+                         "algorithmic_bytes_per_launch": (iso["algorithmic_mb_per_launch"] * 1e6) if iso else None,
+                         "timed_region": {"achieved": conc, "frac": conc / peak, "avg_launch_us": (1e3 * ms / nt) if nt else None,
+                                          "launches_per_step": n / max(args.steps, 1), "timed_launches": nt,
+                                          "note": "every 8th launch of the dominant class bracketed by HIP events INSIDE the timed region; with "
+                                                  "streams_per_gpu > 1 a launch shares the GPU with the other sub-batch's kernels, so its "
+                                                  "duration includes that overlap (not a kernel-quality figure)"},
+                         "classes": table},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out))
+        if parity is not None and parity.get("ok") is False:
+            log("PARITY CHECK FAILED")
     if args.save_out:
         import numpy as np
         os.makedirs(args.save_out, exist_ok=True)
@@ -419,6 +503,8 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity is not None and parity.get("ok") is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

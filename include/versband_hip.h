@@ -42,12 +42,15 @@ const char* vb_last_error(void);
 int vb_abi_version(void);
 
 /* HIP-event timing of one kernel class inside a region (bench.py roofline): bit 0 = bf16 GEMM,
- * bit 1 = attention, bit 2 = fp32 conv.  Events are recorded on the launch stream around every launch of
+ * bit 1 = attention, bit 2 = conv1d, bit 3 = fused ResBlock pair.  Events are recorded on the launch stream around every launch of
  * the enabled classes; vb_prof_read synchronises the device and sums the elapsed times.
  * Bits 8..15 of class_mask = sampling period n (time every n-th launch of a class per host thread; 0/1 = every launch).
- * vb_prof_read: ms_sum and flops cover the `timed` launches only; `launches` counts all launches of the class. */
+ * vb_prof_read: ms_sum, flops and bytes (algorithmic work of those launches) cover the `timed` launches only; `launches` counts all launches of the class. */
+/* Tuning / A-B knobs (environment variables VB_GEMM_TILE, VB_BAND_UNFUSED, ...) are read once per process; a tool or test
+ * that changes one at run time calls this afterwards.  Not needed by a product caller. */
+void vb_tune_reload(void);
 int vb_prof_enable(int class_mask);
-int vb_prof_read(int cls, double* ms_sum, double* flops, int64_t* launches, int64_t* timed);
+int vb_prof_read(int cls, double* ms_sum, double* flops, double* bytes, int64_t* launches, int64_t* timed);
 
 /* ---------------------------------------------------------------- DiT + Band-MoE ----
  * TxtFlagLargeImprovedDiTV2 (ldm/modules/diffusionmodules/vocal2music_moe.py:293-520),
@@ -149,7 +152,7 @@ int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void
 int vb_euler_cfg_step(float* x, const float* v, int B, int64_t per_item, float cfg_scale, float dt, int has_uncond, void* stream);
 
 /* CFMSampler.sample_cfg (ldm/models/diffusion/cfm1_audio_sampler.py:87-116): n_steps Euler steps.
- *   t_idx_table int64[n_steps], dt_table f32[n_steps] : HOST arrays
+ *   t_idx_table int64[n_steps], dt_table f32[n_steps] : host OR device arrays (copied with hipMemcpyDefault on the stream; host arrays must outlive that copy)
  *   noise: NULL or per-step injected noise laid out [step][depth][rows][w]
  *   traj  optional f32 [n_steps+1][B][C][T] */
 int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps,

@@ -1,0 +1,61 @@
+"""Oracle digest of the BENCHMARKED workload (test infrastructure; imported by nothing in the product path).
+
+bench.py draws its router noise on the device (counter-based stream keyed by seed / global clip / evaluation / block / gate);
+versband_amd.prng.device_router_exponentials restates that stream on the host, so the CPU oracle can replay clip 0 of
+bench.py's first timed pass exactly: 50 CFG Euler steps at T = 752, L = 80, scale 3, then the VAE decode.  The result is
+committed as tests/golden/bench_clip0.npz (the oracle's latent in full + a digest of its mel) and bench.py / the GPU tests
+compare the HIP path's bf16 production output with it at north_star's tolerances.
+
+    python oracle/gen_bench_digest.py            # ~1-2 min of CPU
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_cpu  # noqa: E402
+from tests.helpers import clip_batch  # noqa: E402
+from versband_amd import prng, synth  # noqa: E402
+
+SEED, T, L, E, DEPTH, STEPS, SCALE = 1234, 752, 80, 4, 4, 50, 3.0
+
+
+def digest(a, prefix, n_samples=256):
+    """fingerprint in the key layout tests/helpers.check_digest reads (same definition as oracle/gen_golden.py:digest)"""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    idx = (np.arange(n_samples, dtype=np.int64) * 2654435761 + 12345) % a.size
+    d = {"shape_numel": np.array([a.size], dtype=np.int64), "sum": np.array([a.sum()]), "l2": np.array([np.sqrt((a * a).sum())]),
+         "maxabs": np.array([np.abs(a).max()]), "idx": idx, "val": a[idx]}
+    return {prefix + k: v for k, v in d.items()}
+
+
+def device_noise(seed, clip, nfe, branch):
+    out = []
+    for blk in range(DEPTH):
+        out.append(tuple(torch.from_numpy(prng.device_router_exponentials(seed, clip, nfe, branch, blk, gate, T, w))
+                         for gate, w in ((0, 2), (1, E), (2, E))))
+    return out
+
+
+def main():
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    dcfg, vcfg = synth.DiTConfig(), synth.VAEConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1)
+    inp = clip_batch(1, T, L, clip0=0, seed=SEED)
+    cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
+    cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], inp["midi"], inp["beats"], T)
+    z = ref_cpu.sample_cfg(sd, inp["x_latent"], cc, cu, SCALE, STEPS + 1, lambda k, br: device_noise(SEED, 0, k, br))
+    mel = ref_cpu.vae_decode(sdv, z)
+    out = {"meta": np.array([SEED, T, L, E, STEPS], dtype=np.int64), "scale": np.float32(SCALE), "z": z.numpy()}
+    out.update(digest(mel, "mel_"))
+    path = os.path.join(ROOT, "tests", "golden", "bench_clip0.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,9 @@ def parse_args():
     p.add_argument("--synthetic_frames", type=int, default=1500)
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "split"])
     p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--dummy_text", action="store_true",
+                   help="text captions get seeded stand-in embeddings instead of FLAN-T5 (no T5 weights / tokenizer needed); without "
+                        "this flag a caption that cannot be encoded is an error")
     p.add_argument("--eval_mel", action="store_true",
                    help="re-analyse every written accompaniment with the MelNet front-end (HIP) and report mel L1 against the decoded "
                         "mel and, when the item has one, the ground-truth accompaniment's mel (mel_l1.tsv)")
@@ -74,6 +77,8 @@ class SyntheticDataset:
 def initialize_model(args, device):
     config = load_config(args.config)
     config.model.params["precision"] = args.precision
+    if args.dummy_text:
+        config.model.params["cond_stage_config"]["params"]["dummy_text"] = True
     model = instantiate_from_config(config.model)
     if args.ckpt:
         sd = torch.load(args.ckpt, map_location="cpu")["state_dict"]

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = L.load()                      # builds with hipcc if the in-tree .so is absent
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.vb_abi_version() == 1
+    assert lib.vb_abi_version() == 2
     assert lib.vb_last_error() is not None
 
 

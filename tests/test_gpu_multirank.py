@@ -27,7 +27,7 @@ def _bench(args, env_extra, timeout=900):
 
 
 def test_two_ranks_one_command_match_single_process(tmp_path):
-    common = ["--steps", "1", "--warmup", "1", "--flow-steps", "3", "--streams", "1", "--no-cpu-baseline"]
+    common = ["--steps", "1", "--warmup", "1", "--flow-steps", "3", "--streams", "1", "--no-cpu-baseline", "--no-isolated"]
     d2, d1 = str(tmp_path / "w2"), str(tmp_path / "w1")
     out2 = _bench(["--gpus", "2", "--batch", "2", "--save-out", d2] + common, {"VB_BENCH_ONE_DEVICE": "1"})
     assert out2["n_gpus"] == 2 and out2["ranks"]["world"] == 2 and out2["ranks"]["weight_broadcast_bytes"] > 5e8

@@ -13,6 +13,7 @@ import torch
 
 from oracle import ref_cpu
 from tests.helpers import SEED, check_digest, clip_batch, describe, exp_noise, gumbel_arrays, gumbel_arrays_steps, rel_l2
+from versband_amd import _lib as L
 from versband_amd import model as vm
 from versband_amd import synth
 
@@ -267,9 +268,12 @@ def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
     outs = []
     for cfg in ("22", "33"):
         monkeypatch.setenv("VB_GEMM_TILE", cfg)
+        L.load().vb_tune_reload()
         v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
         torch.cuda.synchronize()
         outs.append((v.clone(), r.clone()))
+    monkeypatch.delenv("VB_GEMM_TILE")
+    L.load().vb_tune_reload()
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0])
 
@@ -286,8 +290,11 @@ def test_fused_band_experts_match_two_gemm_path(engines, monkeypatch):
     torch.cuda.synchronize()
     v1, r1 = v1.clone(), r1.clone()
     monkeypatch.setenv("VB_BAND_UNFUSED", "1")
+    L.load().vb_tune_reload()
     v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=4, return_routes=True)
     torch.cuda.synchronize()
+    monkeypatch.delenv("VB_BAND_UNFUSED")
+    L.load().vb_tune_reload()
     assert torch.equal(r1, r2)
     assert torch.equal(v1, v2), describe("fused vs two-GEMM band experts", v1, v2)
 

@@ -111,8 +111,18 @@ def test_factory_and_checkpoint_plumbing(tmp_path):
     # get_learned_conditioning passes pre-computed T5 embeddings through and keeps the acoustic dict
     c = m.get_learned_conditioning({"caption": torch.zeros(2, 80, 1024), "acoustic": {"midi": 1}, "name": ["a", "b"]})
     assert c["caption"].shape == (2, 80, 1024) and c["acoustic"] == {"midi": 1}
+    # text captions without T5 weights / tokenizer: loud failure (the reference would fail in from_pretrained), never silent noise
+    with pytest.raises(RuntimeError, match="dummy_text"):
+        m.get_learned_conditioning({"caption": ["Style: pop", ""], "acoustic": {}, "name": ["a", "b"]})
+    m.cond_stage_model.dummy_text = True                   # explicit opt-in (cond_stage_config params / --dummy_text)
     c = m.get_learned_conditioning({"caption": ["Style: pop", ""], "acoustic": {}, "name": ["a", "b"]})
     assert c["caption"].shape == (2, 80, 1024)
+    c2 = m.get_learned_conditioning({"caption": ["Style: pop", ""], "acoustic": {}, "name": ["a", "b"]})
+    assert torch.equal(c["caption"], c2["caption"]) and not torch.equal(c["caption"][0], c["caption"][1])
+    # .to(device) reaches the text encoder too (one GPU per process, scripts/test_final.py initialize_model)
+    m.to("cuda:3")
+    assert str(m.cond_stage_model.device) == "cuda:3"
+    m.to("cpu")
 
 
 def test_vocoder_checkpoint_discovery(tmp_path):

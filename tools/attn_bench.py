@@ -6,6 +6,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from versband_amd import _lib as L  # noqa: E402
+from versband_amd import _lib as _vbL
 
 lib = L.load()
 B, H, hd, Lc = 16, 8, 96, 80
@@ -19,7 +20,7 @@ for T in (752, 376):
     for name, use_self in (("self+cross", True), ("cross-only", False)):
         line = f"T={T} {name:10s}:"
         for abl, nm in ((0, "full"), (1, "noKVload"), (2, "noSoftmax"), (3, "noPV"), (4, "noQK")):
-            os.environ["VB_ATTN_ABLATE"] = str(abl)
+            _vbL.set_tuning(VB_ATTN_ABLATE=str(abl))
 
             def run():
                 L.check(lib.vb_attention(L.ptr(q), L.ptr(k) if use_self else None, L.ptr(vt) if use_self else None, L.ptr(ky), L.ptr(vyt),
@@ -37,4 +38,4 @@ for T in (752, 376):
             fl = 4.0 * B * H * T * hd * ((T if use_self else 0) + Lc)
             line += f"  {nm}: {us:6.1f}us" + (f" ({fl / us / 1e6:4.0f}TF)" if abl == 0 else "")
         print(line, flush=True)
-os.environ["VB_ATTN_ABLATE"] = "0"
+_vbL.set_tuning(VB_ATTN_ABLATE="0")

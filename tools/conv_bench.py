@@ -7,6 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from versband_amd import _lib as L  # noqa: E402
 from versband_amd import pack  # noqa: E402
+from versband_amd import _lib as _vbL
 
 lib = L.load()
 B = 8
@@ -30,7 +31,7 @@ for Ci, Co, T, k, dil, res, act in cases:
     flops = 2.0 * B * Co * Ci * k * T
     byts = 4.0 * B * T * (Ci + Co * (2 if res else 1))
     for split, cfgv in ((False, 0), (True, 0), (True, 1), (True, 2), (True, 3), (True, 4)):
-        os.environ['VB_CONV_ABLATE'] = str(cfgv)
+        _vbL.set_tuning(VB_CONV_ABLATE=str(cfgv))
 
         def run():
             L.check(lib.vb_conv1d_f32(L.ptr(x), L.ptr(wp), L.ptr(b), B, Ci, T, Co, k, dil, pad, 1, 0, 0, T, act, 0.1,

@@ -3,6 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from versband_amd import _lib as L
+from versband_amd import _lib as _vbL
 lib = L.load()
 for M, N, K in ((12032, 2304, 768), (6016, 2304, 768)):
     A = torch.randn(1, M, K, device="cuda").to(torch.bfloat16)
@@ -10,7 +11,7 @@ for M, N, K in ((12032, 2304, 768), (6016, 2304, 768)):
     C = torch.empty(M, N, device="cuda")
     ref, line = None, f"{M}x{N}x{K}:"
     for c in (0, 6, 3, 9, 0, 6):
-        os.environ["VB_GEMM_NCHUNK"] = str(c)
+        _vbL.set_tuning(VB_GEMM_NCHUNK=str(c))
         for _ in range(3):
             L.check(lib.vb_gemm_bf16(L.ptr(A), L.ptr(B), None, M, N, K, 1, L.ptr(C), L.stream_ptr()), "gemm")
         torch.cuda.synchronize()

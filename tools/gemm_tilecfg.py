@@ -6,6 +6,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from versband_amd import _lib as L  # noqa: E402
+from versband_amd import _lib as _vbL
 
 lib = L.load()
 _w = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
@@ -22,9 +23,9 @@ for M, N, K in shapes:
     line = f"{M:6d}x{N:5d}x{K:4d}:"
     for cfg in ("22", "33", "24", "42", ""):
         if cfg:
-            os.environ["VB_GEMM_TILE"] = cfg
+            _vbL.set_tuning(VB_GEMM_TILE=cfg)
         else:
-            os.environ.pop("VB_GEMM_TILE", None)
+            _vbL.set_tuning(VB_GEMM_TILE=None)
         Cd.zero_()
         for _ in range(10):
             L.check(lib.vb_gemm_bf16(L.ptr(A), L.ptr(B), None, M, N, K, 1, L.ptr(Cd), L.stream_ptr()), "gemm")

@@ -6,6 +6,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from versband_amd import _lib as L  # noqa: E402
+from versband_amd import _lib as _vbL
 
 lib = L.load()
 N, K = 768, 768
@@ -22,7 +23,7 @@ for mt in (21, 42, 85, 94, 128, 170, 256, 21, 42, 64, 85, 94, 106, 128, 150, 170
     Cd = torch.empty(M, N, device="cuda")
     line = f"M={M:6d} tiles={mt * 6:5d} ({mt * 6 / 256:4.2f}/CU):"
     for abl, nm in ((0, "full"), (4, "noStore"), (1, "noDMA"), (5, "noLoop")):
-        os.environ["VB_GEMM_ABLATE"] = str(abl)
+        _vbL.set_tuning(VB_GEMM_ABLATE=str(abl))
         for _ in range(20):
             lib.vb_gemm_bf16(L.ptr(A), L.ptr(B), None, M, N, K, 1, L.ptr(Cd), L.stream_ptr())
         torch.cuda.synchronize()
@@ -33,5 +34,5 @@ for mt in (21, 42, 85, 94, 128, 170, 256, 21, 42, 64, 85, 94, 106, 128, 150, 170
         e1.record()
         torch.cuda.synchronize()
         line += f"  {nm}: {e0.elapsed_time(e1) * 1e3 / 100:6.1f}us"
-    os.environ["VB_GEMM_ABLATE"] = "0"
+    _vbL.set_tuning(VB_GEMM_ABLATE="0")
     print(line, flush=True)

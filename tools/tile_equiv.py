@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import clip_batch  # noqa: E402
 from versband_amd import synth  # noqa: E402
 from versband_amd.engine import Context, DiTEngine  # noqa: E402
+from versband_amd import _lib as _vbL
 
 dev = torch.device("cuda:0")
 dcfg = synth.DiTConfig()
@@ -21,7 +22,7 @@ cond = eng.precompute_cond(t5, inp["midi"].to(dev), inp["beats"].to(dev), T)
 t_idx = torch.full((2 * B,), 500, dtype=torch.int64)
 outs = {}
 for cfg in ("22", "33"):
-    os.environ["VB_GEMM_TILE"] = cfg
+    _vbL.set_tuning(VB_GEMM_TILE=cfg)
     v, r = eng.forward(inp["x_latent"].to(dev), t_idx, cond, seed=3, return_routes=True)
     torch.cuda.synchronize()
     outs[cfg] = (v.clone(), r.clone())

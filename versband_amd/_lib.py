@@ -89,8 +89,9 @@ PROTOTYPES = {
     "vb_ctx_destroy": (c_int, [P]),
     "vb_last_error": (C.c_char_p, []),
     "vb_abi_version": (c_int, []),
+    "vb_tune_reload": (None, []),
     "vb_prof_enable": (c_int, [c_int]),
-    "vb_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "vb_prof_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(c_i64), C.POINTER(c_i64)]),
     "vb_dit_load": (c_int, [P, C.POINTER(DitConfig), C.POINTER(DitWeights)]),
     "vb_dit_cond_bytes": (c_size_t, [C.POINTER(DitConfig), c_int, c_int, c_int, c_int]),
     "vb_dit_workspace_bytes": (c_size_t, [C.POINTER(DitConfig), c_int, c_int, c_int, c_int]),
@@ -140,10 +141,14 @@ def load(build_if_missing: bool = True):
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
-    if not os.path.exists(LIB_PATH):
-        if not build_if_missing:
-            raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
-        from .build import build
+    from .build import build, is_current
+    if not os.path.exists(LIB_PATH) and not build_if_missing:
+        raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
+    if not is_current():
+        # missing OR built from other sources (the digest covers csrc/ and the public header): never run a stale binary - an ABI
+        # struct mismatch would be memory corruption, not an error.  hipcc cross-compiles, so this works without a GPU too.
+        if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            raise VersbandError(f"{LIB_PATH} is missing or stale and hipcc is not available to rebuild it")
         build()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
@@ -152,6 +157,17 @@ def load(build_if_missing: bool = True):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_tuning(**knobs):
+    """Flip VB_* tuning knobs at run time (tools / A-B tests): the library reads its environment once per process, so the
+    change is followed by vb_tune_reload().  set_tuning(VB_GEMM_TILE="33"); a value of None removes the variable."""
+    for k, v in knobs.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    load().vb_tune_reload()
 
 
 def check(rc: int, what: str = ""):

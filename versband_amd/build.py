@@ -30,11 +30,17 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def is_current() -> bool:
+    """the in-tree library exists and was built from exactly the sources on disk"""
+    stamp = os.path.join(OBJ, "digest.txt")
+    return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == _digest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     stamp = os.path.join(OBJ, "digest.txt")
     dg = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dg:
+    if not force and is_current():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -275,13 +275,14 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     d.B = a.B; d.T = a.T; d.Tpad = a.Tpad; d.L = a.L; d.Lpad = a.Lpad; d.H = a.H; d.D = a.H * a.hd;
     d.has_self = a.has_self; d.has_cross = a.has_cross; d.kv_batch_mod = a.kv_batch_mod;
     d.scale_log2e = a.scale * 1.4426950408889634f;
-    ProfScope prof(1, 4.0 * a.B * a.H * a.T * a.hd * ((a.has_self ? a.T : 0) + (a.has_cross ? a.L : 0)), st);
+    const double ae = (double)a.B * a.H * a.hd * 2.0 * a.q.np;      // bytes per token (or key) row of one q/k/v/out tensor
+    ProfScope prof(1, 4.0 * a.B * a.H * a.T * a.hd * ((a.has_self ? a.T : 0) + (a.has_cross ? a.L : 0)),
+                   ae * (2.0 * a.T + (a.has_self ? 2.0 * a.T : 0) + (a.has_cross ? 2.0 * a.L : 0)), st);
     d.nq = cdiv(a.T, 128);
     dim3 grid(d.nq * ((a.B * a.H + 7) / 8 * 8));
     if (a.q.np == 2) hipLaunchKernelGGL((attn_kernel<true, 0>), grid, dim3(256), 0, st, d);
     else {
-        const char* ea = getenv("VB_ATTN_ABLATE");
-        const int abl = ea ? atoi(ea) : 0;
+        const int abl = vb_tune().attn_ablate;
         if (abl == 1) hipLaunchKernelGGL((attn_kernel<false, 1>), grid, dim3(256), 0, st, d);
         else if (abl == 2) hipLaunchKernelGGL((attn_kernel<false, 2>), grid, dim3(256), 0, st, d);
         else if (abl == 3) hipLaunchKernelGGL((attn_kernel<false, 3>), grid, dim3(256), 0, st, d);

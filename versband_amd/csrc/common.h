@@ -71,4 +71,25 @@ extern thread_local char g_vb_err[512];
         if (r__ != VB_OK) return r__; \
     } while (0)
 
+// Tuning / A-B knobs (environment variables VB_*), read ONCE per process instead of at every launch; tools and tests that flip a
+// knob at run time call vb_tune_reload() (exported, not part of the product ABI) after changing the environment.
+struct VbTune {
+    int gemm_tile = -1, gemm_variant = 1, gemm_ablate = 0, gemm_nchunk = 0, gemm_p8 = -1;
+    int conv_cfg = 0, conv_ablate = 0, attn_ablate = 0, attn_variant = -1;
+    bool gate_unfolded = false, stem_f32 = false, band_unfused = false, moe_unfused = false, no_graph = false;
+};
+const VbTune& vb_tune();
+
+// "first launch of this kernel on the CURRENT device": per-device once-flags for hipFuncSetAttribute (a process normally owns one
+// GPU, but nothing here may silently depend on that)
+struct OnceFlags { bool seen[64] = {}; };
+static inline bool vb_first_use_on_device(OnceFlags& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    if (f.seen[d]) return false;
+    f.seen[d] = true;
+    return true;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

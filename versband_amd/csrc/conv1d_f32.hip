@@ -469,8 +469,7 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg_x3(const ConvDev& d, int n_count, int B, hipStream_t st) {
     dim3 grid(cdiv(n_count, WN * TN * 32), cdiv(d.Co, WM * TM * 32), B * d.phases);
-    const char* ea = getenv("VB_CONV_ABLATE");
-    const int abl = ea ? atoi(ea) : 0;
+    const int abl = vb_tune().conv_ablate;
     if (abl == 1) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, d);
     else if (abl == 2) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, d);
     else if (abl == 3) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 3>), grid, dim3(256), 0, st, d);
@@ -509,12 +508,14 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if ((d.ntaps - 1) * d.dil > XHALO) VB_FAIL(VB_E_INVALID, "conv1d: halo %d exceeds %d", (d.ntaps - 1) * d.dil, XHALO);
     if (a.out_transposed && (a.Co % 4)) VB_FAIL(VB_E_INVALID, "conv1d: transposed output needs Co%%4==0");
     if ((a.in_act == ACT_GN_SWISH || a.in_act == ACT_GN) && (a.Ci % a.gn_groups)) VB_FAIL(VB_E_INVALID, "conv1d: Ci %% groups");
-    ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * (a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize), st);
+    const double taps_eff = a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize;
+    ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * taps_eff,
+                   4.0 * a.B * ((double)a.Ci * a.T_in * (a.xt ? 1.0 : 1.0) + (double)a.Co * a.T_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.beta != 0.f ? 1.0 : 0.0)))
+                       + 4.0 * (double)a.Co * a.Ci * (a.tr_stride > 1 ? a.tr_k : a.ksize), st);
     if (a.wp && (!a.w_bstride || a.wp_bstride)) {
         if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
         // VB_CONV_CFG (tuning knob): 1 = wide-T tile (64co x 256t) for 32 < Co <= 64
-        const char* ev = getenv("VB_CONV_CFG");
-        const int cfgv = ev ? atoi(ev) : 0;
+        const int cfgv = vb_tune().conv_cfg;
         // one workgroup of the 128co x 256t tile per CU (92 KB LDS): a grid a little over 256 workgroups (every VAE level at
         // B = 8 makes 288) runs as two rounds at 56 % - the 128co x 128t tile (71 KB, two per CU) halves the granule
         const int64_t blocks = (int64_t)cdiv(n_count, 256) * cdiv(a.Co, 128) * a.B * d.phases;

@@ -3,6 +3,7 @@
 // VAE decoder and the HiFi-GAN generator, and the extern "C" entry points of
 // include/versband_hip.h.  No device allocation happens here: all scratch is carved out of
 // caller buffers (sizes from *_bytes()).
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -13,21 +14,51 @@
 
 thread_local char g_vb_err[512] = "";
 
+// ---- tuning knobs ---------------------------------------------------------------------------
+static VbTune g_tune;
+static bool g_tune_loaded = false;
+static std::mutex g_tune_mu;
+static int env_int(const char* k, int dflt) { const char* v = getenv(k); return (v && *v) ? atoi(v) : dflt; }
+static void tune_load() {
+    VbTune t;
+    t.gemm_tile = env_int("VB_GEMM_TILE", -1); t.gemm_variant = env_int("VB_GEMM_VARIANT", 1); t.gemm_ablate = env_int("VB_GEMM_ABLATE", 0);
+    t.gemm_nchunk = env_int("VB_GEMM_NCHUNK", 0); t.gemm_p8 = env_int("VB_GEMM_P8", -1);
+    t.conv_cfg = env_int("VB_CONV_CFG", 0); t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
+    t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
+    t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
+    t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr; t.moe_unfused = getenv("VB_MOE_UNFUSED") != nullptr;
+    t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
+    g_tune = t;
+    g_tune_loaded = true;
+}
+const VbTune& vb_tune() {
+    if (!g_tune_loaded) {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        if (!g_tune_loaded) tune_load();
+    }
+    return g_tune;
+}
+extern "C" void vb_tune_reload(void) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tune_load();
+}
+
 // ---- kernel-class profiling -----------------------------------------------------------------
-#define PROF_CLASSES 3
+#define PROF_CLASSES 4
 #define PROF_POOL 32768
 static int g_prof_mask = 0;
 static std::vector<hipEvent_t> g_prof_ev;          // pool of events (pairs)
 static size_t g_prof_next = 0;
 struct ProfRec { int cls; size_t ev; };
 static std::vector<ProfRec> g_prof_recs;
-static double g_prof_flops[PROF_CLASSES] = {0, 0, 0};
-static long long g_prof_launches[PROF_CLASSES] = {0, 0, 0};
+static double g_prof_flops[PROF_CLASSES] = {0, 0, 0, 0};
+static double g_prof_bytes[PROF_CLASSES] = {0, 0, 0, 0};
+static long long g_prof_launches[PROF_CLASSES] = {0, 0, 0, 0};
 static thread_local size_t g_prof_open = (size_t)-1;
-static thread_local unsigned g_prof_tick[PROF_CLASSES] = {0, 0, 0};
+static thread_local unsigned g_prof_tick[PROF_CLASSES] = {0, 0, 0, 0};
 static int g_prof_every = 1;                        // time every n-th launch of a class (per host thread)
 static std::mutex g_prof_mu;                        // several host threads (one per stream) may launch concurrently
-void prof_start(int cls, double flops, hipStream_t st) {
+void prof_start(int cls, double flops, double bytes, hipStream_t st) {
     g_prof_open = (size_t)-1;
     if (!(g_prof_mask & (1 << cls))) return;
     const bool sampled = (g_prof_tick[cls]++ % (unsigned)g_prof_every) == 0;
@@ -35,6 +66,7 @@ void prof_start(int cls, double flops, hipStream_t st) {
     g_prof_launches[cls] += 1;
     if (!sampled || g_prof_next + 2 > g_prof_ev.size()) return;      // counted, not timed
     g_prof_flops[cls] += flops;
+    g_prof_bytes[cls] += bytes;
     g_prof_open = g_prof_next;
     g_prof_next += 2;
     (void)hipEventRecord(g_prof_ev[g_prof_open], st);
@@ -98,7 +130,7 @@ struct CondL {
 };
 static inline bool gate_fold_ok(const vb_dit_config& c, int L) {
     const int NS = L * c.heads;
-    return NS % 64 == 0 && NS <= 1024 && NS <= c.hidden && (c.heads & (c.heads - 1)) == 0 && c.heads <= 64 && getenv("VB_GATE_UNFOLDED") == nullptr;
+    return NS % 64 == 0 && NS <= 1024 && NS <= c.hidden && (c.heads & (c.heads - 1)) == 0 && c.heads <= 64 && !vb_tune().gate_unfolded;
 }
 static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T, int L) {
     CondL o;
@@ -128,6 +160,7 @@ static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T
     return o;
 }
 
+#define T_FREQ_ROWS 1000  // rows of vb_dit_weights.t_freq_table (pack.timestep_table); other indices are computed in the kernel
 #define PRE_STEPS 64      // sampler steps whose adaLN / gate vectors are tabulated up front
 struct WsL {
     int* step; int64_t* t_idx_cur; int64_t* t_table; float* dt_table;
@@ -231,7 +264,7 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
         cv.w = which ? w.beats_conv_w : w.midi_conv_w; cv.bias = which ? w.beats_conv_b : w.midi_conv_b;
         cv.Co = D; cv.ksize = 5; cv.pad = 2; cv.out = which ? s.tC : s.tB; cv.out_bstride = (int64_t)D * T_mel; cv.T_out = T_mel;
         cv.out_act = ACT_LRELU; cv.out_slope = 0.01f; cv.B = B;
-        if (const void* w3 = which ? w.beats_conv_w3 : w.midi_conv_w3; w3 && D % 32 == 0 && !getenv("VB_STEM_F32")) {
+        if (const void* w3 = which ? w.beats_conv_w3 : w.midi_conv_w3; w3 && D % 32 == 0 && !vb_tune().stem_f32) {
             cv.wp = (const bf16_t*)w3; cv.Ci_pad = D; cv.wp_plane = (int64_t)5 * D * D;
         }
         VB_TRY(launch_conv1d(cv, st));
@@ -240,7 +273,7 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
     cv = ConvArgs();
     cv.x = s.tD; cv.x_bstride = (int64_t)D * T_ac; cv.Ci = D; cv.T_in = T_ac; cv.w = w.final_proj_w; cv.bias = w.final_proj_b;
     cv.Co = D; cv.ksize = 1; cv.pad = 0; cv.out = s.tE; cv.out_bstride = (int64_t)D * T_ac; cv.T_out = T_ac; cv.B = B;
-    if (w.final_proj_w3 && D % 32 == 0 && !getenv("VB_STEM_F32")) { cv.wp = (const bf16_t*)w.final_proj_w3; cv.Ci_pad = D; cv.wp_plane = (int64_t)D * D; }
+    if (w.final_proj_w3 && D % 32 == 0 && !vb_tune().stem_f32) { cv.wp = (const bf16_t*)w.final_proj_w3; cv.Ci_pad = D; cv.wp_plane = (int64_t)D * D; }
     VB_TRY(launch_conv1d(cv, st));
     VB_TRY(launch_transpose_bct_btc(s.tE, B, D, T_ac, T, cd.ac, st));
 
@@ -326,7 +359,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     if (pre_mod) {
         mod_all = pre_mod; hl = pre_hl; hl_ld = 0;
     } else {
-        VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, t_idx, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, Beff, D, 256, 0, s.temb0, D, st));
+        VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, t_idx, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, Beff, D, 256, 0, s.temb0, D, st, T_FREQ_ROWS));
         VB_TRY(launch_gemv_rows(s.temb0, D, nullptr, 0, 1, w.t_mlp2_w, w.t_mlp2_b, Beff, D, D, 1, s.temb, D, st));
         VB_TRY(launch_gemv_rows(s.temb, D, cd.cemb, D, Beff, w.adaln_w, w.adaln_b, Beff, MODW, D, 1, s.mod_all, MODW, st));
         VB_TRY(launch_gemv_rows(s.temb, D, nullptr, 0, 1, w.hl_w, w.hl_b, Beff, c.depth * 2, D, 0, s.hl, c.depth * 2, st));
@@ -424,7 +457,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         g.y32_in = s.y32; g.row_scale = s.ma; g.out = y; g.ldc = D;
         VB_TRY(launch_gemm(g, st));
         // band experts (frequency-MoE): expert e sees only channel band e and produces only band e
-        const bool band_unfused = getenv("VB_BAND_UNFUSED") != nullptr;       // tuning / A-B switch (tests compare both)
+        const bool band_unfused = vb_tune().band_unfused;       // tuning / A-B switch (tests compare both)
         if (np == 1 && band == 192 && H % 64 == 0 && E <= 8 && 8 % E == 0 && !band_unfused) {
             // both products in one launch, hidden kept in LDS (bf16 production mode; independent of the batch size)
             BandFfnArgs bf;
@@ -576,7 +609,7 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
 extern "C" {
 
 const char* vb_last_error(void) { return g_vb_err; }
-int vb_abi_version(void) { return 1; }
+int vb_abi_version(void) { return 2; }
 
 int vb_prof_enable(int class_mask) {
     if (class_mask && g_prof_ev.empty()) {
@@ -587,10 +620,10 @@ int vb_prof_enable(int class_mask) {
     g_prof_every = ((class_mask >> 8) & 0xff) > 0 ? ((class_mask >> 8) & 0xff) : 1;     // bits 8..15: sampling period
     g_prof_next = 0;
     g_prof_recs.clear();
-    for (int i = 0; i < PROF_CLASSES; ++i) { g_prof_flops[i] = 0; g_prof_launches[i] = 0; }
+    for (int i = 0; i < PROF_CLASSES; ++i) { g_prof_flops[i] = 0; g_prof_bytes[i] = 0; g_prof_launches[i] = 0; }
     return VB_OK;
 }
-int vb_prof_read(int cls, double* ms_sum, double* flops, int64_t* launches, int64_t* timed) {
+int vb_prof_read(int cls, double* ms_sum, double* flops, double* bytes, int64_t* launches, int64_t* timed) {
     if (cls < 0 || cls >= PROF_CLASSES) VB_FAIL(VB_E_INVALID, "prof_read: class %d", cls);
     VB_HIP(hipDeviceSynchronize());
     double ms = 0; int64_t n = 0;
@@ -600,7 +633,7 @@ int vb_prof_read(int cls, double* ms_sum, double* flops, int64_t* launches, int6
         VB_HIP(hipEventElapsedTime(&t, g_prof_ev[r.ev], g_prof_ev[r.ev + 1]));
         ms += t; ++n;
     }
-    *ms_sum = ms; *flops = g_prof_flops[cls]; *launches = g_prof_launches[cls]; *timed = n;
+    *ms_sum = ms; *flops = g_prof_flops[cls]; *bytes = g_prof_bytes[cls]; *launches = g_prof_launches[cls]; *timed = n;
     return VB_OK;
 }
 
@@ -671,8 +704,9 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
     WsL s = carve_ws(ws, c, B, n_branch, T, L);
     const int Beff = B * n_branch;
     const int64_t per = (int64_t)c.in_channels * T;
-    VB_HIP(hipMemcpyAsync(s.t_table, t_idx_table, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    VB_HIP(hipMemcpyAsync(s.dt_table, dt_table, (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice, st));
+    // (tables may live on the host or on the device; a host caller must keep them alive until the stream has consumed them)
+    VB_HIP(hipMemcpyAsync(s.t_table, t_idx_table, (size_t)n_steps * sizeof(int64_t), hipMemcpyDefault, st));
+    VB_HIP(hipMemcpyAsync(s.dt_table, dt_table, (size_t)n_steps * sizeof(float), hipMemcpyDefault, st));
     VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * c.np * sizeof(bf16_t), st));
     if (traj) VB_HIP(hipMemcpyAsync(traj, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
     // The timestep embedding, every block's adaLN modulation and the high-level gate logits depend on (t_k, caption)
@@ -682,7 +716,7 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
     if (tab) {
         const vb_dit_weights& w = ctx->w;
         CondL cd = carve_cond(const_cast<void*>(cond), c, B, n_branch, T, L);
-        VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, s.t_table, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, n_steps, D, 256, 0, s.temb0_s, D, st));
+        VB_TRY(launch_gemv_rows_idx(w.t_freq_table, 256, s.t_table, nullptr, 0, 1, w.t_mlp0_w, w.t_mlp0_b, n_steps, D, 256, 0, s.temb0_s, D, st, T_FREQ_ROWS));
         VB_TRY(launch_gemv_rows(s.temb0_s, D, nullptr, 0, 1, w.t_mlp2_w, w.t_mlp2_b, n_steps, D, D, 1, s.temb_s, D, st));
         VB_TRY(launch_iota_div(s.row_step, n_steps * Beff, Beff, st));
         if (w.adaln_wp) {

@@ -830,8 +830,7 @@ template <int EPI, int TM, int TN, int NSTB>
 static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NSTB * (64 * TM + 64 * TN) * 128;
     if constexpr (EPI == EPI_F32 && TM == 3 && TN == 3) {
-        const char* ea = getenv("VB_GEMM_ABLATE");
-        const int abl = ea ? atoi(ea) : 0;
+        const int abl = vb_tune().gemm_ablate;
         if (abl >= 1 && abl <= 3) {
             auto k = abl == 1 ? gemm_bf16_big_kernel<EPI, TM, TN, NSTB, 1> : (abl == 2 ? gemm_bf16_big_kernel<EPI, TM, TN, NSTB, 2> : gemm_bf16_big_kernel<EPI, TM, TN, NSTB, 3>);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -840,11 +839,9 @@ static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
         }
     }
     static_assert(lds >= (size_t)64 * (64 * TN + 4) * 4, "epilogue staging slab must fit in the ring");
-    static bool attr = false;
-    if (!attr) {
+    static OnceFlags attr;
+    if (vb_first_use_on_device(attr))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
     hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), grid, dim3(NTHREADS), lds, st, d);
 }
 
@@ -852,10 +849,8 @@ template <int EPI>
 static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     // VB_GEMM_VARIANT (tuning knob): 0 register-staged, 1 DMA BK=64 x2 stages, 2 DMA BK=32 x4 stages, 3 DMA BK=32 x3 stages,
     // 4 DMA BK=64 x3 stages.  Default 1 (fastest on the DiT shapes, tools/gemm_bench.py).
-    const char* ev = getenv("VB_GEMM_VARIANT");
-    const int variant = ev ? atoi(ev) : 1;
-    const char* ea = getenv("VB_GEMM_ABLATE");
-    const int abl = ea ? atoi(ea) : 0;
+    const int variant = vb_tune().gemm_variant;
+    const int abl = vb_tune().gemm_ablate;
     if constexpr (EPI == EPI_F32) {
         if (abl == 1 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 1>), grid, dim3(NTHREADS), 0, st, d); return; }
         if (abl == 2 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 2>), grid, dim3(NTHREADS), 0, st, d); return; }
@@ -1069,12 +1064,11 @@ int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
     const int per8 = 8 / a.E;                         // row tiles per group of 8 consecutive blocks
     const int nblk = cdiv(row_tiles, per8) * 8;
     constexpr size_t lds = (size_t)BF_BM * 128 + 8 * 16384;   // hidden chunk (24 KB) + 8 ring slots of 16 KB = 152 KB
-    static bool attr = false;
-    if (!attr) {
+    static OnceFlags attr;
+    if (vb_first_use_on_device(attr))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    ProfScope prof(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H), st);
+    ProfScope prof(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H),
+                   (double)a.M * a.E * a.band * (2.0 + 8.0) + (double)a.E * 3.0 * a.H * a.band * 2.0, st);
     hipLaunchKernelGGL(band_ffn_kernel, dim3(nblk), dim3(NTHREADS), lds, st, d);
     VB_CHECK_LAUNCH();
     return VB_OK;
@@ -1099,14 +1093,25 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.rT = 1.0f / (float)d.T; d.rhd = 1.0f / (float)d.hd; d.rD = 1.0f / (float)d.D;
     if (a.M >= (1 << 21) || (int64_t)a.N * (a.ngroups > 0 ? a.ngroups : 1) >= (1 << 21)) VB_FAIL(VB_E_INVALID, "gemm: index ranges exceed fdiv()");
     d.trace = g_gemm_trace;
-    ProfScope prof(0, 2.0 * a.M * a.N * a.K * ((a.group_off || a.ngroups <= 1) ? 1 : a.ngroups), st);
+    const double gz_ = (a.group_off || a.ngroups <= 1) ? 1.0 : (double)a.ngroups;        // groups that share the row range multiply the work
+    const double npl_ = a.nseg == 3 ? 2.0 : 1.0, MN_ = (double)a.M * a.N * gz_;
+    double ob_;                                                                         // result (+ read-modify) bytes of the epilogue
+    switch (a.epi) {
+        case EPI_F32: case EPI_F32_CT: case EPI_SCATTER_F32: ob_ = 4.0 * MN_; break;
+        case EPI_RESID_GATE: ob_ = 8.0 * MN_; break;
+        case EPI_SWIGLU: case EPI_GEGLU: ob_ = MN_ * a.out.np; break;
+        case EPI_SCATTER_ADD_PLANES: ob_ = MN_ * (4.0 + 2.0 * a.out.np); break;
+        case EPI_QKV_ROPE: ob_ = 2.0 * MN_ * a.q.np; break;
+        default: ob_ = 2.0 * MN_ * a.out.np; break;
+    }
+    ProfScope prof(0, 2.0 * MN_ * a.K,
+                   2.0 * npl_ * ((double)a.M * a.K * (a.a_koff_group ? gz_ : 1.0) + (double)a.N * a.K * (a.ngroups > 1 ? a.ngroups : 1)) + ob_, st);
     // tile configuration: 0 = 128x128 (two workgroups per CU), else (TM, TN) of the big-tile kernel (one per CU).  The
     // big tiles are taken when K allows the DMA ring; among them the one that wastes the fewest tile-slots of the last
     // round of 256 CUs and of partial edge tiles wins.  VB_GEMM_TILE=22|33|24|42 overrides (tuning).
     int cfg = 0;
     if (a.K % 64 == 0) {
-        const char* et = getenv("VB_GEMM_TILE");
-        const int forced = et ? atoi(et) : -1;
+        const int forced = vb_tune().gemm_tile;
         if (forced >= 0) cfg = forced == 22 ? 0 : forced;
         else {
             // measured (tools/gemm_tilecfg.py): the 192x192 kernel wins when its tiles fit one round of the 256 CUs
@@ -1125,8 +1130,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
     d.ncc = 0; d.rpx = (mt + 7) / 8;
     if (!cfg && !a.group_off) {       // VB_GEMM_NCHUNK=c (tuning, default off until measured in the pipeline): column chunking for wide N
-        const char* ec = getenv("VB_GEMM_NCHUNK");
-        const int c = ec ? atoi(ec) : 0;
+        const int c = vb_tune().gemm_nchunk;
         if (c > 0 && d.n_tiles > c && d.n_tiles % c == 0) d.ncc = c;
     }
 #define VB_GEMM_CASE(E) \

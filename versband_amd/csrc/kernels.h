@@ -143,7 +143,8 @@ int launch_planes_to_f32(Planes in, int64_t n, float* out, hipStream_t st);
 int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias,
                      int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st);
 int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* W,
-                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st);
+                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st, int sin_rows = 0);
+// (sin_rows > 0: x is the timestep-sinusoid table with that many rows; indices outside it are evaluated on the fly)
 int launch_mean_rows(const float* x, int B, int L, int D, float* out, hipStream_t st);
 int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, float* out, hipStream_t st);
 int launch_pool_add(const float* a, const float* b, int B, int C, int T_in, float* out, hipStream_t st);
@@ -172,12 +173,14 @@ int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n
 int launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 
 // ---------------------------------------------------------------------------
-// per-kernel-class HIP-event timing (bench.py roofline): 0 = gemm, 1 = attention, 2 = conv
+// per-kernel-class HIP-event timing (bench.py roofline): 0 = bf16 GEMM (incl. the fused expert kernels), 1 = attention,
+// 2 = conv1d (VAE + vocoder), 3 = fused ResBlock pair.  flops / bytes = ALGORITHMIC work of the launch (2 x MACs; operand +
+// result bytes touched once), the figures DESIGN.md section 4 states per kernel.
 // ---------------------------------------------------------------------------
-void prof_start(int cls, double flops, hipStream_t st);
+void prof_start(int cls, double flops, double bytes, hipStream_t st);
 void prof_stop(int cls, hipStream_t st);
 struct ProfScope {
     int cls; hipStream_t st;
-    ProfScope(int c, double flops, hipStream_t s) : cls(c), st(s) { prof_start(c, flops, s); }
+    ProfScope(int c, double flops, double bytes, hipStream_t s) : cls(c), st(s) { prof_start(c, flops, bytes, s); }
     ~ProfScope() { prof_stop(cls, st); }
 };

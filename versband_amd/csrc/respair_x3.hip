@@ -239,7 +239,8 @@ int launch_respair(const RespairArgs& a, hipStream_t st) {
     const int TT = RP_T - (a.k - 1);
     dim3 grid(cdiv(a.T, TT), 1, a.B);
     // two convolutions' worth of flops (the recomputed halo of conv1 is not counted)
-    ProfScope prof(2, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T, st);
+    ProfScope prof(3, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T,
+                   4.0 * a.B * (double)a.C * a.T * (2.0 + (a.beta != 0.f ? 1.0 : 0.0)) + 2.0 * 4.0 * a.k * a.C * a.C, st);
     // (a persistent variant with both convolutions' weights resident in LDS and the next window prefetched was measured slower,
     //  460 / 900 / 1100 us against 440 / 620 / 830 us for k = 3 / 7 / 11: one workgroup per CU cannot hide its own phase latencies)
     if (a.C == 32) hipLaunchKernelGGL(respair_x3_kernel<1>, grid, dim3(256), 0, st, d);

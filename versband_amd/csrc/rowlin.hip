@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) rowlin_kernel(const float* __restrict__ x
                                                     const float* __restrict__ x2, int x2_ld, int x2_mod,
                                                     const float* shift, const float* scale, int mod_ld, int T, float eps,
                                                     const float* __restrict__ W, const float* __restrict__ bias, int R, int N, int K,
-                                                    int act_in, int n_per_block, float* out, int out_ld) {
+                                                    int act_in, int n_per_block, float* out, int out_ld, int sin_rows) {
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [RL_R][K + 4]
     const int KP = K + 4;
     const int r0 = blockIdx.y * RL_R;
@@ -27,7 +27,15 @@ __global__ void __launch_bounds__(256) rowlin_kernel(const float* __restrict__ x
             float v = 0.f;
             if (r < nr) {
                 int64_t xr = x_row_idx ? x_row_idx[r0 + r] : (int64_t)(r0 + r);
-                v = x[xr * x_ld + k];
+                if (sin_rows > 0 && (xr < 0 || xr >= sin_rows)) {
+                    // x is the tabulated timestep sinusoid ([cos | sin] of t * exp(-ln(1e4) i / half), flag_large_dit_moe.py:110-128):
+                    // an index outside the table (stochastic_encode-style callers pass t up to num_timesteps) is computed, never read
+                    const int half = K >> 1, i = k < half ? k : k - half;
+                    const float a = (float)xr * expf(-9.210340371976184f * (float)i / (float)half);
+                    v = k < half ? cosf(a) : sinf(a);
+                } else {
+                    v = x[xr * x_ld + k];
+                }
                 if (x2) v += x2[(int64_t)((r0 + r) % x2_mod) * x2_ld + k];
                 if (act_in == 1) v = v / (1.f + expf(-v));
             }
@@ -87,7 +95,7 @@ __global__ void __launch_bounds__(256) rowlin_kernel(const float* __restrict__ x
 template <int MODE>
 static int launch_rowlin(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* shift,
                          const float* scale, int mod_ld, int T, float eps, const float* W, const float* bias, int R, int N, int K,
-                         int act_in, float* out, int out_ld, hipStream_t st) {
+                         int act_in, float* out, int out_ld, hipStream_t st, int sin_rows = 0) {
     if (K % 8 || K > 4096) VB_FAIL(VB_E_INVALID, "rowlin: K=%d must be %%8 and <= 4096", K);
     // slab of outputs per block: enough blocks to fill the chip, at least 16 outputs (one pass of the 4 waves)
     const int row_groups = cdiv(R, RL_R);
@@ -95,20 +103,18 @@ static int launch_rowlin(const float* x, int x_ld, const int64_t* idx, const flo
     while (npb > 16 && (int64_t)cdiv(N, npb) * row_groups < 512) npb >>= 1;
     dim3 grid(cdiv(N, npb), row_groups);
     size_t sh = (size_t)RL_R * (K + 4) * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[MODE]) {
+    static OnceFlags attr_set[2];
+    if (vb_first_use_on_device(attr_set[MODE]))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set[MODE] = true;
-    }
     hipLaunchKernelGGL(rowlin_kernel<MODE>, grid, dim3(256), sh, st, x, x_ld, idx, x2, x2_ld, x2_mod > 0 ? x2_mod : 1, shift, scale, mod_ld,
-                       T > 0 ? T : 1, eps, W, bias, R, N, K, act_in, npb, out, out_ld);
+                       T > 0 ? T : 1, eps, W, bias, R, N, K, act_in, npb, out, out_ld, sin_rows);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
 
 int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const float* x2, int x2_ld, int x2_mod, const float* W,
-                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
-    return launch_rowlin<0>(x, x_ld, idx, x2, x2_ld, x2_mod, nullptr, nullptr, 0, 1, 0.f, W, bias, R, N, K, act_in, out, out_ld, st);
+                         const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st, int sin_rows) {
+    return launch_rowlin<0>(x, x_ld, idx, x2, x2_ld, x2_mod, nullptr, nullptr, 0, 1, 0.f, W, bias, R, N, K, act_in, out, out_ld, st, sin_rows);
 }
 int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias, int R,
                      int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {

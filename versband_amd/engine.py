@@ -57,13 +57,14 @@ class DiTEngine:
     precision "bf16"  : plain bf16 MFMA operands (production / benchmark)
     precision "split" : bf16x3 split operands (fp32-class, parity tests)"""
 
-    def __init__(self, ctx: Context, cfg: DiTConfig, state_dict: Dict[str, Tensor], precision: str = "bf16"):
+    def __init__(self, ctx: Context, cfg: DiTConfig, state_dict: Dict[str, Tensor], precision: str = "bf16", share: "DiTEngine" = None):
         assert precision in ("bf16", "split")
         ctx = Context(ctx.device)        # a vb_ctx holds ONE loaded DiT: every engine owns its handle
         self.ctx, self.cfg, self.precision = ctx, cfg, precision
         self.np = 2 if precision == "split" else 1
         dev = ctx.device
-        self.packed = pack.pack_dit(state_dict, cfg, self.np, dev)
+        # engines of one process that serve different sub-batches share ONE packed copy of the weights (`share`)
+        self.packed = share.packed if share is not None and share.precision == precision else pack.pack_dit(state_dict, cfg, self.np, dev)
         self.ccfg = L.DitConfig(cfg.in_channels, cfg.hidden_size, cfg.num_heads, cfg.depth, cfg.num_experts, cfg.ffn_hidden,
                                 cfg.context_dim, cfg.ori_dim, cfg.max_len, self.np, cfg.norm_eps)
         w = L.DitWeights()
@@ -77,6 +78,8 @@ class DiTEngine:
         L.check(ctx.lib.vb_dit_load(ctx.handle, C.byref(self.ccfg), C.byref(w)), "vb_dit_load")
         self._ws: Optional[Tensor] = None
         self._ws_key = None
+        self._checked: Dict[Tuple[int, int, int], bool] = {}     # (data_ptr, version, numel) of index tracks already range-checked
+        self._tables: Dict[tuple, Tuple[Tensor, Tensor]] = {}    # device copies of the (t_idx, dt) step tables
 
     # -- buffers -----------------------------------------------------------
     def _workspace(self, B, nb, T, Lc) -> Tensor:
@@ -98,8 +101,16 @@ class DiTEngine:
         Beff, Lc, _ = t5.shape
         nb = Beff // B
         assert nb * B == Beff and nb in (1, 2)
-        if midi.min() < 0 or midi.max() >= 130 or beats.min() < 0 or beats.max() >= 3:
-            raise IndexError("midi/beats index out of range of the embedding tables (130 / 3 rows)")
+        # range check of the embedding indices: ONE device->host read per new pair of tracks (identity + version), none when the
+        # same tensors come back (a serving loop / the benchmark re-submits resident inputs and must not sync the stream)
+        key = (midi.data_ptr(), midi._version, beats.data_ptr(), beats._version, midi.numel())
+        if key not in self._checked:
+            lim = torch.stack([midi.min(), midi.max(), beats.min(), beats.max()]).tolist()
+            if lim[0] < 0 or lim[1] >= 130 or lim[2] < 0 or lim[3] >= 3:
+                raise IndexError("midi/beats index out of range of the embedding tables (130 / 3 rows)")
+            if len(self._checked) > 64:
+                self._checked.clear()
+            self._checked[key] = True
         n = self.ctx.lib.vb_dit_cond_bytes(C.byref(self.ccfg), B, nb, T, Lc)
         cond = torch.empty(n, dtype=torch.uint8, device=dev)
         ws = self._workspace(B, nb, T, Lc)
@@ -141,14 +152,17 @@ class DiTEngine:
         B, nb, T, Lc = cond["B"], cond["nb"], cond["T"], cond["L"]
         x = x0.to(dev, torch.float32).contiguous().clone()
         n = len(t_idx_table)
-        tt = (C.c_int64 * n)(*[int(v) for v in t_idx_table])
-        dd = (C.c_float * n)(*[float(v) for v in dt_table])
+        tkey = (tuple(int(v) for v in t_idx_table), tuple(float(v) for v in dt_table))
+        if tkey not in self._tables:            # step tables live on the device: nothing on the host has to outlive the async launch
+            if len(self._tables) > 16:
+                self._tables.clear()
+            self._tables[tkey] = (torch.tensor(tkey[0], dtype=torch.int64, device=dev), torch.tensor(tkey[1], dtype=torch.float32, device=dev))
+        tt, dd = self._tables[tkey]
         traj = torch.empty(n + 1, *x.shape, dtype=torch.float32, device=dev) if return_traj else None
         ns, keep = self._noise_struct(noise, seed, clip_base, 0)
         ws = self._workspace(B, nb, T, Lc)
-        L.check(self.ctx.lib.vb_sample_cfg(self.ctx.handle, L.ptr(x), L.ptr(cond["buf"]), B, nb, T, Lc, n, tt, dd, float(scale),
+        L.check(self.ctx.lib.vb_sample_cfg(self.ctx.handle, L.ptr(x), L.ptr(cond["buf"]), B, nb, T, Lc, n, L.ptr(tt), L.ptr(dd), float(scale),
                                            C.byref(ns), L.ptr(traj), L.ptr(ws), L.stream_ptr()), "vb_sample_cfg")
-        torch.cuda.current_stream().synchronize()   # host tables (tt, dd) must outlive the async copies
         return (x, traj) if return_traj else x
 
 

@@ -64,6 +64,12 @@ def sample_long(engine, x0: Tensor, t5_cond: Tensor, t5_uncond: Tensor, midi: Te
     nw = len(plan)
     n = plan[0][1]
     midi, beats = midi.reshape(B, -1), beats.reshape(B, -1)
+    if midi.shape[1] != beats.shape[1] or abs(midi.shape[1] - 2 * T) > 4:
+        raise ValueError(f"midi/beats tracks of {midi.shape[1]} / {beats.shape[1]} frames do not match 2 x {T} latent frames")
+    if midi.shape[1] < 2 * T:         # a slightly shorter track: repeat the last frame, as the stem does for |T - T_mel/2| <= 2
+        pad = 2 * T - midi.shape[1]
+        midi = torch.cat([midi, midi[:, -1:].expand(B, pad)], dim=1)
+        beats = torch.cat([beats, beats[:, -1:].expand(B, pad)], dim=1)
     # windows become extra batch rows: row = w * B + b
     xw = torch.cat([x0[:, :, s:s + n] for s, _ in plan], dim=0)
     mw = torch.cat([midi[:, 2 * s:2 * (s + n)] for s, _ in plan], dim=0)

@@ -164,11 +164,15 @@ class DiffusionWrapper:
 
 class FrozenTextVocalEmbedder:
     """ldm/modules/encoders/modules.py:194-233 boundary: returns {'caption': [B,L,1024] f32, 'acoustic', 'name'}.
-    The FLAN-T5 encoder is upstream of the accelerated path; captions given as
-    pre-computed embeddings pass through, strings get seeded dummy embeddings (BASELINE: dummy T5)."""
+    Captions given as pre-computed embeddings pass through; token ids run the T5 encoder stack on the HIP library; strings
+    are tokenized (the sentencepiece tokenizer under `version`) and encoded like the reference does (modules.py:216-221).
+    When strings arrive and the T5 weights or the tokenizer are missing this RAISES - the reference would have failed in
+    from_pretrained(version) too.  Seeded stand-in embeddings for strings (BASELINE's "dummy T5 emb") are an explicit
+    opt-in: `dummy_text=True` in the cond_stage_config params (scripts/test_final.py --dummy_text)."""
 
-    def __init__(self, version="google/flan-t5-large", device="cuda", max_length=77, freeze=True, **kw):
+    def __init__(self, version="google/flan-t5-large", device="cuda", max_length=77, freeze=True, dummy_text=False, **kw):
         self.version, self.max_length, self.device = version, max_length, device
+        self.dummy_text = bool(dummy_text)
         self.width = 1024
         self.t5_state: Dict[str, Tensor] = {}
         self.t5_heads, self.t5_eps = 16, 1e-6           # flan-t5-large / t5-v1_1-large encoder
@@ -187,15 +191,21 @@ class FrozenTextVocalEmbedder:
     def _t5_engine(self):
         from .engine import Context, T5Engine
         if self._t5 is None:
-            dev = self.device if str(self.device).startswith("cuda:") else "cuda:0"
+            dev = self.device if str(self.device).startswith("cuda:") else f"cuda:{torch.cuda.current_device()}"
             self._t5 = T5Engine(Context(dev), self.t5_state, num_heads=self.t5_heads, eps=self.t5_eps)
         return self._t5
 
     def _tokenize(self, caps: List[str]) -> Optional[Tensor]:
         """The tokenizer is upstream of the library; it is used when the checkpoint directory named by `version` is on disk."""
-        if self._tokenizer is None and os.path.isdir(self.version):
-            from transformers import T5Tokenizer
-            self._tokenizer = T5Tokenizer.from_pretrained(self.version)
+        if self._tokenizer is None:
+            # `version` is a path relative to where the reference is launched from (useful_ckpts/flan-t5-large): try the cwd,
+            # then the repository root
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            for cand in (self.version, os.path.join(root, self.version)):
+                if os.path.isdir(cand):
+                    from transformers import T5Tokenizer
+                    self._tokenizer = T5Tokenizer.from_pretrained(cand)
+                    break
         if self._tokenizer is None:
             return None
         enc = self._tokenizer(text=caps, truncation=True, max_length=self.max_length, return_length=True, return_overflowing_tokens=False,
@@ -221,7 +231,15 @@ class FrozenTextVocalEmbedder:
             cap = self._t5_engine().encode(cap)
         elif not torch.is_tensor(cap):
             ids = self._tokenize(list(cap)) if self.t5_state else None
-            cap = self._t5_engine().encode(ids) if ids is not None else self._embed_text(list(cap))
+            if ids is not None:
+                cap = self._t5_engine().encode(ids)
+            elif self.dummy_text:
+                cap = self._embed_text(list(cap))
+            else:
+                what = "no cond_stage_model.transformer.* weights are loaded" if not self.t5_state else \
+                    f"the tokenizer directory {self.version!r} does not exist"
+                raise RuntimeError(f"FrozenTextVocalEmbedder: text captions given but {what}; pass pre-computed T5 embeddings / token "
+                                   "ids, load a checkpoint with the T5 encoder, or opt in to seeded stand-in embeddings with dummy_text=True")
         return {"caption": cap.float(), "acoustic": c["acoustic"], "name": c.get("name")}
 
 
@@ -248,6 +266,7 @@ class CFM:
         self._ctx = None
         self._dit = None
         self._cond_cache: Dict[int, Any] = {}
+        self._nfe = 0                     # apply_model calls so far: keys the on-device router noise of each call
 
     # -- checkpoint (scripts/test_final.py:143) ----------------------------
     def load_state_dict(self, sd: Dict[str, Tensor], strict: bool = False):
@@ -277,6 +296,8 @@ class CFM:
 
     def to(self, device):
         self.device = torch.device(device)
+        if hasattr(self.cond_stage_model, "to"):
+            self.cond_stage_model.to(self.device)        # the reference does cond_stage_model.to(model.device): one GPU per process
         return self
 
     # -- engines -----------------------------------------------------------
@@ -315,7 +336,9 @@ class CFM:
         return self.cond_stage_model(c)
 
     def _precompute(self, conds: List[dict], T: int):
-        key = tuple(id(c) for c in conds) + (T,)
+        def sig(t):       # identity AND content version of a tensor: an in-place edit or a swapped tensor invalidates the entry
+            return (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else id(t)
+        key = tuple((id(c), sig(c["caption"]), sig(c["acoustic"].get("midi")), sig(c["acoustic"].get("beats"))) for c in conds) + (T,)
         hit = self._cond_cache.get(key)
         if hit is not None:
             return hit[0]
@@ -331,7 +354,11 @@ class CFM:
         if not isinstance(cond, dict):
             raise NotImplementedError("only the hybrid dict conditioning of configs/vocal2music.yaml is supported")
         pc = self._precompute([cond], x_noisy.shape[-1])
-        v = self.dit_engine().forward(x_noisy, t, pc, seed=int(torch.initial_seed()) & 0xFFFFFFFF)
+        # every call draws fresh Gumbel router noise like the reference's gumbel_softmax does: the counter-based draws are keyed
+        # by (seed, clip, evaluation index, block, gate), so the evaluation index advances per call
+        v = self.dit_engine().forward(x_noisy, t, pc, seed=int(torch.initial_seed()) & 0xFFFFFFFF, nfe=self._nfe)
+        self._nfe += 1
+        # lb_loss (vocal2music_moe.py:427-429) is a training-only auxiliary; the inference callers discard it
         return v, torch.zeros((), device=v.device)
 
     @torch.no_grad()

@@ -63,8 +63,12 @@ def pack_conv_x3(w_packed: Tensor, ci_multiple: int = 32):
 def fold_weight_norm(g: Tensor, v: Tensor) -> Tensor:
     """weight_norm(dim=0): w = g * v / ||v|| (the reference never removes weight norm:
     vocoder/hifigan/hifigan.py:15-18, so checkpoints carry weight_g / weight_v)."""
+    # always on the host: the norm's reduction order differs between CPU and GPU kernels, and a rank that received its
+    # checkpoint by broadcast (device tensors) must fold to the same bits as a single process that read it from disk
+    dev = v.device
+    g, v = g.detach().float().cpu(), v.detach().float().cpu()
     n = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
-    return v * (g / n)
+    return (v * (g / n)).to(dev)
 
 
 def timestep_table(n: int = 1000, dim: int = 256, max_period: float = 10000.0) -> Tensor:

@@ -75,3 +75,31 @@ def exponential(seed: int, n: int, offset: int = 0) -> np.ndarray:
 def randint(seed: int, n: int, lo: int, hi: int, offset: int = 0) -> np.ndarray:
     """int64 uniform integers in [lo, hi)."""
     return (lo + (bits64(seed, n, offset) % np.uint64(hi - lo)).astype(np.int64)).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------
+# The library's own router-noise stream (csrc/elementwise.hip: gumbel_draw), restated on the host so that a production run
+# (noise drawn on the device, keyed by (seed, global clip, evaluation, branch, block, gate, token, slot)) can be replayed by
+# the CPU oracle.  The integer pipeline is exact; u -> Exp(1) uses float32 log1p like the kernel (a last-ulp libm difference
+# moves a Gumbel value by ~1e-7 relative: it can flip a hard route only at an exact near-tie).
+# ---------------------------------------------------------------------------
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def device_router_exponentials(seed: int, clip: int, nfe: int, branch: int, block: int, gate: int, T: int, width: int) -> np.ndarray:
+    """Exp(1) draws E [T, width] float32 with  -log(E) == the Gumbel value gumbel_draw() returns for the same key."""
+    u64 = np.uint64
+    with np.errstate(over="ignore"):
+        key = _splitmix64(u64(seed & 0xFFFFFFFFFFFFFFFF) ^ _splitmix64(u64(clip) * _GOLD + u64(0x1234567)))
+        key = _splitmix64(key + (u64((nfe * 2 + branch) << 20)) + (u64(block) << u64(8)) + u64(gate))
+        idx = np.arange(1, T * width + 1, dtype=np.uint64)
+        z = _splitmix64(key + idx * _GOLD)
+    u = ((z >> u64(40)) + u64(1)).astype(np.float32) * np.float32(1.0 / 16777218.0)
+    ex = np.maximum(-np.log1p(-u, dtype=np.float32), np.float32(1e-30))
+    return ex.reshape(T, width)
