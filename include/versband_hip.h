@@ -158,6 +158,10 @@ int vb_euler_cfg_step(float* x, const float* v, int B, int64_t per_item, float c
 int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps,
                   const int64_t* t_idx_table, const float* dt_table, float cfg_scale, const vb_noise* noise, float* traj,
                   void* ws, void* stream);
+/* The step loop of vb_sample_cfg is captured into a hipGraph the second time a call arrives with the same buffers / shape on a
+ * capturable (non-default) stream and replayed from then on (noise key via device memory: any seed / clip base replays).
+ * Number of instantiated graphs this context holds (0 = every call so far ran eagerly): */
+int vb_sample_graphs(vb_ctx* ctx);
 
 /* ---------------------------------------------------- conv nets (VAE decoder, HiFi-GAN) ----
  * AutoencoderKL.decode (ldm/models/autoencoder1d.py:55-58, Decoder1D :480-512) and

@@ -256,6 +256,45 @@ def test_determinism_and_clip_keyed_noise(engines):
     assert torch.equal(a[sel], c), describe("clip 2 alone vs in batch", c, a[sel])
 
 
+def test_sampler_graph_replay_equals_eager(ctx, sds, monkeypatch):
+    """vb_sample_cfg captures its step loop into a hipGraph the second time a call arrives with the same buffers on a capturable
+    stream and replays it afterwards; the noise key (seed / clip base) travels through device memory, so replays with OTHER seeds
+    must equal eager runs of those seeds bit for bit.  A stale persistent conditioning handle is refused."""
+    from versband_amd._lib import VersbandError
+    from versband_amd.engine import DiTEngine
+    eng = DiTEngine(ctx, synth.DiTConfig(), sds[4], precision="bf16")
+    B, T, Lc = 2, 120, 16
+    inp = clip_batch(B, T, Lc)
+    t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]]).cuda()
+    midi, beats = inp["midi"].cuda(), inp["beats"].cuda()
+    idx, dts = vm.euler_tables(6)
+    stream = torch.cuda.Stream()
+    outs = {}
+    with torch.cuda.stream(stream):
+        for rep, seed in enumerate((5, 5, 9, 13)):
+            cond = eng.precompute_cond(t5, midi, beats, T, persistent=True)
+            outs[(seed, rep)] = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=seed, clip_base=rep)
+        stream.synchronize()
+        assert eng.graphs() == 1, "the repeated call was not captured"
+        stale = cond
+        eng.precompute_cond(t5, midi, beats, T, persistent=True)
+        with pytest.raises(VersbandError):
+            eng.sample_cfg(inp["x_latent"], stale, idx, dts, 3.0, seed=5)
+    monkeypatch.setenv("VB_NO_GRAPH", "1")
+    L.load().vb_tune_reload()
+    eager = DiTEngine(ctx, synth.DiTConfig(), sds[4], precision="bf16", share=eng)
+    with torch.cuda.stream(stream):
+        for rep, seed in enumerate((5, 5, 9, 13)):
+            cond = eager.precompute_cond(t5, midi, beats, T, persistent=True)
+            ref = eager.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=seed, clip_base=rep)
+            stream.synchronize()
+            assert torch.equal(ref, outs[(seed, rep)]), describe(f"graph replay vs eager, seed {seed} call {rep}", outs[(seed, rep)], ref)
+    assert eager.graphs() == 0
+    monkeypatch.delenv("VB_NO_GRAPH")
+    L.load().vb_tune_reload()
+    assert not torch.equal(outs[(5, 1)], outs[(9, 2)])
+
+
 def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
     """The launcher picks the GEMM tile shape (128x128 two-per-CU kernel or the 192x192 one-per-CU kernel) from the
     problem size, i.e. from the batch: both must produce bit-identical DiT outputs and routes, otherwise a clip's
@@ -276,6 +315,29 @@ def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
     L.load().vb_tune_reload()
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+def test_eight_wave_gemm_matches_four_wave_kernels(engines, monkeypatch):
+    """The launcher takes the 8-wave 256x256 ping-pong kernel for large problems and the 4-wave kernels for small ones (one clip):
+    both walk K in the same MFMA order and share the epilogue code, so every epilogue of the DiT (QKV+RoPE, gated residual, fp32
+    scores, grouped SwiGLU with row gather, row-scatter / scatter-add) must give bit-identical outputs and routes."""
+    B, T, Lc = 4, 752, 80
+    inp = clip_batch(B, T, Lc)
+    t_idx = torch.full((2 * B,), 321, dtype=torch.int64)
+    for prec in ("bf16", "split"):
+        eng = engines[(4, prec)]
+        cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+        outs = []
+        for p8 in ("0", "1"):
+            monkeypatch.setenv("VB_GEMM_P8", p8)
+            L.load().vb_tune_reload()
+            v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
+            torch.cuda.synchronize()
+            outs.append((v.clone(), r.clone()))
+        monkeypatch.delenv("VB_GEMM_P8")
+        L.load().vb_tune_reload()
+        assert torch.equal(outs[0][1], outs[1][1]), prec
+        assert torch.equal(outs[0][0], outs[1][0]), describe(f"8-wave vs 4-wave GEMM ({prec})", outs[1][0], outs[0][0])
 
 
 def test_fused_band_experts_match_two_gemm_path(engines, monkeypatch):

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "vb_dit_forward": (c_int, [P, P, P, P, C.POINTER(Noise), c_int, c_int, c_int, c_int, P, P, P, P]),
     "vb_euler_cfg_step": (c_int, [P, P, c_int, c_i64, c_float, c_float, c_int, P]),
     "vb_sample_cfg": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, C.POINTER(Noise), P, P, P]),
+    "vb_sample_graphs": (c_int, [P]),
     "vb_net_load": (c_int, [P, c_int, C.POINTER(NetOp), c_int, C.POINTER(BufDesc), c_int, c_int, c_int, c_int, c_int]),
     "vb_net_workspace_bytes": (c_size_t, [P, c_int, c_int, c_int]),
     "vb_vae_decode": (c_int, [P, P, c_int, c_int, P, P, P]),

@@ -290,6 +290,16 @@ __global__ void step_advance_kernel(int* step, int64_t* t_idx_cur, const int64_t
     int k = s < n_steps ? s : n_steps - 1;
     for (int i = threadIdx.x; i < Beff; i += blockDim.x) t_idx_cur[i] = t_table[k];
 }
+// noise key of a sampler call -> the parameter block behind the step counter: step[4..9] = {seed, clip_base, nfe_base} as 3 x int64
+__global__ void sampler_params_kernel(int* step, unsigned long long seed, long long clip_base, int nfe_base) {
+    long long* prm = reinterpret_cast<long long*>(step + 4);
+    prm[0] = (long long)seed; prm[1] = clip_base; prm[2] = nfe_base;
+}
+int launch_sampler_params(int* step, uint64_t seed, int64_t clip_base, int nfe_base, hipStream_t st) {
+    hipLaunchKernelGGL(sampler_params_kernel, dim3(1), dim3(1), 0, st, step, (unsigned long long)seed, (long long)clip_base, nfe_base);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
 int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, int reset, hipStream_t st) {
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, step, t_idx_cur, t_table, n_steps, Beff, reset);
     VB_CHECK_LAUNCH();
@@ -456,6 +466,12 @@ __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __r
     // the counter-based noise generator, the index arithmetic and the arg-max loops run once per PP tokens.
     constexpr int SPT = 64 / PP;
     const bool gen = g1 == nullptr;
+    if (step) {
+        // sampler path: the noise key lives in the device-side parameter block behind the step counter (launch_sampler_params), so
+        // a captured graph of the step loop can be replayed for another seed / clip base without re-capturing
+        const long long* prm = reinterpret_cast<const long long*>(step + 4);
+        seed = (uint64_t)prm[0]; clip_base = prm[1]; nfe_base = (int)prm[2];
+    }
     const int nfe = nfe_base + (step ? *step : 0);
     const int tokq = lane / SPT, sl = lane % SPT, lbase = lane - sl;
 #pragma unroll

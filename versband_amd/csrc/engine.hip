@@ -23,6 +23,7 @@ static void tune_load() {
     VbTune t;
     t.gemm_tile = env_int("VB_GEMM_TILE", -1); t.gemm_variant = env_int("VB_GEMM_VARIANT", 1); t.gemm_ablate = env_int("VB_GEMM_ABLATE", 0);
     t.gemm_nchunk = env_int("VB_GEMM_NCHUNK", 0); t.gemm_p8 = env_int("VB_GEMM_P8", -1);
+    t.gemm_p8_mask = env_int("VB_GEMM_P8_MASK", 0); t.gemm_p8_direct = env_int("VB_GEMM_P8_DIRECT", 0);
     t.conv_cfg = env_int("VB_CONV_CFG", 0); t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
     t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
     t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
@@ -87,8 +88,18 @@ struct NetProgram {
     int in_ch = 0, out_ch = 0, in_tmul = 1, out_tmul = 1;
     bool loaded = false;
 };
+// one captured + instantiated step loop of vb_sample_cfg (hipGraph), keyed by everything the launches bake in
+struct SampleGraph {
+    const void* x = nullptr; const void* cond = nullptr; const void* ws = nullptr;
+    int B = 0, nb = 0, T = 0, L = 0, n_steps = 0; float cfg_scale = 0.f;
+    int seen = 0;                         // calls with this key so far (the first runs eagerly, the second captures)
+    bool failed = false;                  // capture was refused once (e.g. legacy default stream): stay eager
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    uint64_t last_use = 0;
+};
 struct vb_ctx {
     int device = 0;
+    std::vector<SampleGraph> graphs; uint64_t graph_clock = 0;
     bool dit_loaded = false;
     vb_dit_config cfg;
     vb_dit_weights w;
@@ -651,6 +662,11 @@ int vb_ctx_create(int device, vb_ctx** out) {
     return VB_OK;
 }
 int vb_ctx_destroy(vb_ctx* ctx) {
+    if (ctx)
+        for (SampleGraph& g : ctx->graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
     delete ctx;
     return VB_OK;
 }
@@ -693,22 +709,15 @@ int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void
 int vb_euler_cfg_step(float* x, const float* v, int B, int64_t per_item, float cfg_scale, float dt, int has_uncond, void* stream) {
     return launch_euler_cfg(x, v, B, per_item, cfg_scale, nullptr, nullptr, dt, has_uncond, (hipStream_t)stream);
 }
-int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps,
-                  const int64_t* t_idx_table, const float* dt_table, float cfg_scale, const vb_noise* noise, float* traj, void* ws,
-                  void* stream) {
-    if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "sample_cfg: DiT not loaded");
-    if (n_steps < 1 || n_steps > 1024) VB_FAIL(VB_E_INVALID, "sample_cfg: n_steps=%d", n_steps);
-    VB_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
+// the launches of one sampler call after its tables are in place: tabulation of the per-step conditioning vectors, then n_steps x
+// [step bookkeeping, one network evaluation of both CFG branches, Euler + guidance update]   (cfm1_audio_sampler.py:107-116)
+static int sample_steps(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps, float cfg_scale,
+                        const vb_noise* noise, float* traj, void* ws, hipStream_t st) {
     const vb_dit_config& c = ctx->cfg;
     WsL s = carve_ws(ws, c, B, n_branch, T, L);
     const int Beff = B * n_branch;
     const int64_t per = (int64_t)c.in_channels * T;
-    // (tables may live on the host or on the device; a host caller must keep them alive until the stream has consumed them)
-    VB_HIP(hipMemcpyAsync(s.t_table, t_idx_table, (size_t)n_steps * sizeof(int64_t), hipMemcpyDefault, st));
-    VB_HIP(hipMemcpyAsync(s.dt_table, dt_table, (size_t)n_steps * sizeof(float), hipMemcpyDefault, st));
     VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * c.np * sizeof(bf16_t), st));
-    if (traj) VB_HIP(hipMemcpyAsync(traj, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
     // The timestep embedding, every block's adaLN modulation and the high-level gate logits depend on (t_k, caption)
     // only: tabulate them for ALL steps in four launches instead of four GEMVs inside every network evaluation.
     const bool tab = n_steps <= PRE_STEPS;
@@ -741,6 +750,79 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
         if (traj) VB_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * B * per, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     return VB_OK;
+}
+
+int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, int T, int L, int n_steps,
+                  const int64_t* t_idx_table, const float* dt_table, float cfg_scale, const vb_noise* noise, float* traj, void* ws,
+                  void* stream) {
+    if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "sample_cfg: DiT not loaded");
+    if (n_steps < 1 || n_steps > 1024) VB_FAIL(VB_E_INVALID, "sample_cfg: n_steps=%d", n_steps);
+    VB_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const vb_dit_config& c = ctx->cfg;
+    WsL s = carve_ws(ws, c, B, n_branch, T, L);
+    const int64_t per = (int64_t)c.in_channels * T;
+    // (tables may live on the host or on the device; a host caller must keep them alive until the stream has consumed them)
+    VB_HIP(hipMemcpyAsync(s.t_table, t_idx_table, (size_t)n_steps * sizeof(int64_t), hipMemcpyDefault, st));
+    VB_HIP(hipMemcpyAsync(s.dt_table, dt_table, (size_t)n_steps * sizeof(float), hipMemcpyDefault, st));
+    if (traj) VB_HIP(hipMemcpyAsync(traj, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // the noise key travels through device memory (the router reads it behind the step counter): nothing a replayed graph bakes in
+    VB_TRY(launch_sampler_params(s.step, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, st));
+
+    // ---- the step loop as ONE hipGraph (cfm1_audio_sampler.py:107-116 is ~3000 dependent launches at 50 steps): a call whose
+    // buffers and shape were seen before replays the captured, instantiated graph - one host call instead of thousands, which is
+    // what bounds small batches and several concurrent streams (the HIP runtime serialises launches of different host threads).
+    // Eager when: a trajectory or injected noise arrays are requested (parity path), the per-launch HIP-event profiler is on, the
+    // stream cannot capture (legacy default stream), VB_NO_GRAPH is set, or the key is new (its first call also warms every
+    // kernel's one-time attributes outside a capture).
+    const bool graphable = !vb_tune().no_graph && g_prof_mask == 0 && !traj && !(noise && noise->g1) && n_steps <= PRE_STEPS && st != nullptr;
+    if (graphable) {
+        SampleGraph* e = nullptr;
+        for (SampleGraph& gph : ctx->graphs)
+            if (gph.x == x && gph.cond == cond && gph.ws == ws && gph.B == B && gph.nb == n_branch && gph.T == T && gph.L == L &&
+                gph.n_steps == n_steps && gph.cfg_scale == cfg_scale) { e = &gph; break; }
+        if (!e) {
+            if (ctx->graphs.size() >= 8) {          // evict the least recently used entry
+                size_t lru = 0;
+                for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+                if (ctx->graphs[lru].exec) (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
+                if (ctx->graphs[lru].graph) (void)hipGraphDestroy(ctx->graphs[lru].graph);
+                ctx->graphs.erase(ctx->graphs.begin() + lru);
+            }
+            SampleGraph n; n.x = x; n.cond = cond; n.ws = ws; n.B = B; n.nb = n_branch; n.T = T; n.L = L; n.n_steps = n_steps; n.cfg_scale = cfg_scale;
+            ctx->graphs.push_back(n);
+            e = &ctx->graphs.back();
+        }
+        e->last_use = ++ctx->graph_clock;
+        e->seen += 1;
+        if (!e->exec && !e->failed && e->seen >= 2) {
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = sample_steps(ctx, x, cond, B, n_branch, T, L, n_steps, cfg_scale, noise, nullptr, ws, st);
+                hipGraph_t gr = nullptr;
+                const hipError_t ee = hipStreamEndCapture(st, &gr);
+                if (rc == VB_OK && ee == hipSuccess && gr && hipGraphInstantiate(&e->exec, gr, nullptr, nullptr, 0) == hipSuccess) {
+                    e->graph = gr;
+                } else {
+                    if (gr) (void)hipGraphDestroy(gr);
+                    e->exec = nullptr; e->failed = true;
+                    (void)hipGetLastError();
+                }
+            } else {
+                e->failed = true;
+                (void)hipGetLastError();
+            }
+        }
+        if (e->exec) {
+            VB_HIP(hipGraphLaunch(e->exec, st));
+            return VB_OK;
+        }
+    }
+    return sample_steps(ctx, x, cond, B, n_branch, T, L, n_steps, cfg_scale, noise, traj, ws, st);
+}
+int vb_sample_graphs(vb_ctx* ctx) {
+    int n = 0;
+    if (ctx) for (const SampleGraph& g : ctx->graphs) n += g.exec != nullptr;
+    return n;
 }
 
 // ---- T5 text encoder -------------------------------------------------------------------------------

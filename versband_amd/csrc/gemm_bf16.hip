@@ -26,6 +26,7 @@
 #define BN 128
 #define BK 64
 #define NTHREADS 256
+#define P8_MIN_TILES 96     // auto-selection threshold of the 8-wave 256 x 256 kernel (tiles of the launch)
 
 struct GemmDev {
     const bf16_t* A; int64_t a_plane; int lda; const int* a_rows; int a_koff_group;
@@ -183,11 +184,11 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
 }
 
 // the whole epilogue of one wave: rows slab by slab (i), loads of a slab first, then math + stores
-template <int EPI>
-__device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&acc)[2][2], int row_base, int rows_end, int n_base,
+template <int EPI, int TM = 2, int TN = 2>
+__device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&acc)[TM][TN], int row_base, int rows_end, int n_base,
                                               int frow, int fk) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
         const int slot = row_base + i * 32 + frow;
         if (slot >= rows_end) continue;
         int tok = slot; float scale = 1.f;
@@ -195,16 +196,16 @@ __device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&
             tok = p.rows_out[slot];
             scale = p.row_scale[tok];
         }
-        EpiPre pre[2][4];
+        EpiPre pre[TN][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = n_base + j * 32 + q * 8 + fk * 4;
                 if (n < p.N) epi_load<EPI>(p, g, slot, tok, n, pre[j][q]);
             }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = n_base + j * 32 + q * 8 + fk * 4;
@@ -222,13 +223,15 @@ __device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&
 // all stores are full-line transactions.  The V third of the QKV projection is staged TRANSPOSED instead and written as
 // 4 consecutive tokens of one (head, d) row: the per-head V^T image the attention kernel reads, in 8-B pieces of 128-B runs.
 // Needs 64 * (BN + 4) * 4 bytes of LDS (BN * 68 * 4 for the transposed variant).
-template <int EPI, int TM, int TN>
+// (NWC wave columns x 2 wave rows, NT threads: 2 x 2 / 256 for the 4-wave kernels, 4 x 2 / 512 for the 8-wave kernel)
+template <int EPI, int TM, int TN, int NWC = 2, int NT = NTHREADS>
 __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 (&acc)[TM][TN], float* stg, int row0, int rows_end,
                                                 int n0, int tid, int wr, int wc, int frow, int fk) {
-    constexpr int BNB = 64 * TN;
+    static_assert(NT == 128 * NWC, "two wave rows of NWC waves");
+    constexpr int BNB = NWC * 32 * TN;
     constexpr int PITCH = BNB + 4;               // floats; +4 keeps the 16-B column writes of 8 consecutive rows on distinct banks
     constexpr int QPR = BNB / 4;                 // quads per row
-    constexpr int QPT = 64 * QPR / NTHREADS;     // quads per thread per slab
+    constexpr int QPT = 64 * QPR / NT;           // quads per thread per slab
     bool vsec = false;
     if constexpr (EPI == EPI_QKV_ROPE) vsec = n0 >= 2 * p.D && (p.D % BNB) == 0 && (p.T & 3) == 0 && (p.Tpad & 3) == 0;
 #pragma unroll
@@ -247,10 +250,10 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
                     }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_s_barrier();
-                constexpr int IPT = BNB * 16 / NTHREADS;
+                constexpr int IPT = BNB * 16 / NT;
 #pragma unroll
                 for (int k = 0; k < IPT; ++k) {
-                    const int idx = tid + k * NTHREADS;
+                    const int idx = tid + k * NT;
                     const int rq = idx & 15, c = idx >> 4;
                     const int lr = rq * 4;
                     const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
@@ -296,7 +299,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
         int slot_[QC], tok_[QC]; float scale_[QC];
 #pragma unroll
         for (int kk = 0; kk < QC; ++kk) {
-            const int k = kk, idx = tid + (kb + kk) * NTHREADS;
+            const int k = kk, idx = tid + (kb + kk) * NT;
             const int lr = idx / QPR, cq = idx - lr * QPR;
             const int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
             const int n = n0 + cq * 4;
@@ -314,7 +317,7 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
         for (int kk = 0; kk < QC; ++kk) {
             const int k = kk;
             if (slot_[k] < 0) continue;
-            const int idx = tid + (kb + kk) * NTHREADS;
+            const int idx = tid + (kb + kk) * NT;
             const int lr = idx / QPR, cq = idx - lr * QPR;
             const float4 vv = *reinterpret_cast<const float4*>(stg + lr * PITCH + cq * 4);
             float v[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -826,6 +829,296 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
     }
 }
 
+// ---- variant 4: 256 x 256 tiles, 8 waves in two staggered groups ("ping-pong") ------------------------------------
+// What bounds the 4-wave kernels above is the L2 -> LDS feed (52-60 GB/s per CU whatever the ring, section 5 of DESIGN.md): at
+// 64 flop per byte DMA'd (128^2) or 96 (192^2) the MFMA pipe idles half the time, and with one wave per SIMD every barrier, DMA
+// issue and LDS read of a wave is dead time of its SIMD's matrix pipe.  This kernel
+//   * moves 128 flop per byte DMA'd: block tile 256 x 256 (accumulators = half of the CU's register file), 8 waves as 2 (M) x 4
+//     (N), a wave owns 128 x 64 = 4 x 2 MFMA 32x32 tiles;
+//   * keeps (NST-1) ring stages of [256 + 256 rows] x BKT in flight (BKT = 32: five 32-KB stages = all 160 KB of LDS, 128 KB in
+//     flight) with counted vmcnt - never a drain inside the loop;
+//   * runs the two waves of every SIMD in OPPOSITE phases: the wave rows (wr = 0 / 1) are staggered by one s_barrier, so while
+//     one wave issues its 16 MFMAs of a 32-deep sub-stage (512 matrix-pipe cycles, s_setprio 1) its partner reads the 12
+//     fragments of its next sub-stage from LDS, issues its DMA pieces and waits for them - load latency, DMA issue and the
+//     barriers sit beside the partner's MFMAs instead of in front of one's own (MI355X_MICROARCH.md, "Two waves per SIMD").
+// Barrier algebra (k-th s_barrier of group 0 pairs with the k-th of group 1; group 1 executes one extra barrier first):
+//   group 0:  L(0) X M(0) Y L(1) X M(1) Y ...          group 1:  E L(0) X M(0) Y L(1) ...
+//   -> g0's X(u) = g1's Y(u-1), g0's Y(u) = g1's X(u).  Stage t is read by g0 in L_g0(t) and by g1 one half-period later; its
+//   slot is refilled in the L phase of stage t+1 (both groups are past their reads by then), and "stage t+1 has landed
+//   everywhere" is each wave's counted vmcnt in its last L phase of stage t followed by the barrier both groups pass before
+//   either reads it.  Past the end the ring keeps issuing dummy reloads into dead slots so the counts stay uniform.
+// Accumulation order per output element is the same as in every other variant (k ascending in 16-deep MFMA steps): bit-identical.
+// PP = 1: the ping-pong schedule above.  PP = 0: every wave is software-pipelined on its own instead - the fragments of k-step
+// ks+1 are requested before the 8 MFMAs of k-step ks are queued, the DMA pieces of the stage NST-1 ahead are issued between those
+// MFMAs, ONE barrier per ring stage whose latency (and the next stage's first fragment reads) hides behind the last 8 MFMAs of
+// the stage; the two waves of a SIMD are not synchronised against each other and simply fill each other's issue gaps.
+// ABL (tuning only, PP = 0): 1 = no DMA inside the loop, 2 = no fragment reads, 3 = no MFMA, 4 = no barrier, 5 = no epilogue
+template <int EPI, int BKT, int NST, int PP, int ABL = 0, int STG = 1>
+__global__ void __launch_bounds__(512) gemm_bf16_p8_kernel(const GemmDev p) {
+    constexpr int BMP = 256, BNP = 256;
+    constexpr int NSUB = BKT / 32;                 // 32-deep sub-stages per ring stage
+    constexpr int OPB = BMP * BKT * 2;             // bytes of one operand of a stage
+    constexpr int STAGE = 2 * OPB;
+    constexpr int PPW = OPB / 1024 / 8;            // 1-KB DMA pieces per wave per operand per stage
+    constexpr int LPT = 2 * PPW;                   // DMA instructions per wave per stage
+    constexpr int CH = BKT / 8;                    // 16-B chunks per tile row
+    constexpr int RPP = 64 / CH;                   // tile rows per piece
+    static_assert(BKT == 32 || BKT == 64, "BKT");
+    static_assert(NST >= 2 && (NST - 2) * LPT < 64, "ring depth vs vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsp[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    int g = 0, row0, rows_end, tile_n;
+    {
+        const int L = blockIdx.x, nN = p.n_tiles;
+        const int jx = L >> 3;
+        tile_n = jx % nN;
+        int tmg = (jx / nN) * 8 + (L & 7);
+        if (p.group_off) {
+            bool found = false;
+            for (int gi = 0; gi < p.ngroups; ++gi) {
+                int lo = p.group_off[gi], hi = p.group_off[gi + 1];
+                int nt = (hi - lo + BMP - 1) / BMP;
+                if (tmg < nt) { g = gi; row0 = lo + tmg * BMP; rows_end = hi; found = true; break; }
+                tmg -= nt;
+            }
+            if (!found) return;
+        } else {
+            g = blockIdx.z;
+            row0 = tmg * BMP; rows_end = p.M;
+            if (row0 >= rows_end) return;
+        }
+    }
+    const int n0 = tile_n * BNP;
+    const int KT = p.K / BKT;
+    const int total = KT * p.nseg;
+
+    const bf16_t* asrc[PPW]; const bf16_t* bsrc[PPW];
+    {
+        const int rr = lane / CH, cs = lane % CH;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int r = RPP * (wave * PPW + i) + rr;
+            const int c = (BKT == 64) ? (cs ^ ((r >> 1) & 7)) : (cs ^ ((r >> 2) & 3));
+            int slot = row0 + r;
+            if (slot >= rows_end) slot = row0;
+            const int arow = p.a_rows ? p.a_rows[slot] : slot;
+            asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
+            int nrow = n0 + r;
+            if (nrow >= p.N) nrow = 0;
+            bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
+        }
+    }
+    // issue state: stage counter, its ring slot and its (segment, k) position - advanced incrementally (scalar adds / selects, no
+    // division in the loop); past the last stage the position stays on the last one: dummy reloads into dead slots
+    int iss_t = 0, iss_slot = 0, iss_kt = 0, iss_seg = 0;
+    auto issue_pieces = [&](int q0, int q1) {           // DMA pieces [q0, q1) of the current issue stage
+        const int64_t ao = (iss_seg == 1 ? p.a_plane : 0) + iss_kt * BKT;
+        const int64_t bo = (iss_seg == 2 ? p.b_plane : 0) + iss_kt * BKT;
+        unsigned char* sa = ldsp + iss_slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (i < q0 || i >= q1) continue;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ao), (lds_ptr_t)(sa + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + bo), (lds_ptr_t)(sa + OPB + (wave * PPW + i) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue_advance = [&]() {
+        iss_t += 1;
+        iss_slot = iss_slot == NST - 1 ? 0 : iss_slot + 1;
+        if (iss_t < total) {
+            iss_kt += 1;
+            if (iss_kt == KT) { iss_kt = 0; iss_seg += 1; }
+        }
+    };
+    auto issue = [&]() { issue_pieces(0, PPW); issue_advance(); };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    bf16x8 af[2][4], bf[2][2];
+    auto fload = [&](int st, int sub) {
+        const unsigned char* As = ldsp + st * STAGE;
+        const unsigned char* Bs = As + OPB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = (sub * 2 + ks) * 2 + fk;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + j * 32 + frow, c));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 128 + i * 32 + frow, c));
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue();
+    wait_vmcnt<(NST - 2) * LPT>();                 // this wave's pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PP == 0) {
+        constexpr int KS = BKT / 16;               // 16-deep k-steps per ring stage
+        bf16x8 fa[2][4], fb[2][2];
+        auto fload1 = [&](int st_, int ks, int slot) {
+            if constexpr (ABL == 2) { if (st_ >= 0) return; }
+            const unsigned char* As = ldsp + st_ * STAGE;
+            const unsigned char* Bs = As + OPB;
+            const int c = ks * 2 + fk;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + j * 32 + frow, c));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 128 + i * 32 + frow, c));
+        };
+        auto mfma2 = [&](int slot, int i) {
+            if constexpr (ABL == 3) {
+                acc[i][0][0] += (float)fb[slot][0][0] * (float)fa[slot][i][1];
+                acc[i][1][0] += (float)fb[slot][1][2] * (float)fa[slot][i][3];
+                return;
+            }
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][0], fa[slot][i], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[slot][1], fa[slot][i], acc[i][1], 0, 0, 0);
+        };
+        if constexpr (ABL == 2) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fb[sl][j][e] = (bf16_t)(float)(lane + e + j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fa[sl][i][e] = (bf16_t)(float)(lane - e + i);
+            }
+        }
+        if (total > 0) fload1(0, 0, 0);
+        int st = 0;
+        for (int t = 0; t < total; ++t) {
+            const int nst = st == NST - 1 ? 0 : st + 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1;
+                if (ks == KS - 1) {
+                    // stage boundary: my reads of stage t are in registers; after the barrier stage t+1 is here for everyone and
+                    // the slot of stage t may be refilled
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    if constexpr (ABL != 1) wait_vmcnt<(NST - 2) * LPT>();
+                    if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // 8 MFMAs of k-step ks.  The NEXT k-step's fragment reads are issued two MFMAs INTO the batch (not in front of
+                // it): the compiler waits lgkmcnt(0) before a batch's first MFMA, and this way nothing younger than the batch's
+                // own fragments is outstanding at that point - the reads fly under the remaining six MFMAs.  The DMA pieces of
+                // the stage NST-1 ahead go between the MFMA pairs of the stage's first k-step.
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mfma2(cur, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 0) {
+                        if (ks < KS - 1) fload1(st, ks + 1, cur ^ 1);
+                        else fload1(nst, 0, cur ^ 1);        // (past the last stage: a landed dummy reload)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (ABL != 1 && ks == 0 && i < PPW) {
+                        issue_pieces(i, i + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (ks == 0) issue_advance();
+            }
+            st = nst;
+        }
+        wait_vmcnt<0>();
+        if constexpr (ABL == 5) {
+            float sink = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sink += acc[i][0][0] + acc[i][1][9];
+            if (sink == 12345.678f) p.out32[0] = sink;
+            return;
+        }
+        if constexpr (STG) staged_epilogue<EPI, 4, 2, 4, 512>(p, g, acc, reinterpret_cast<float*>(ldsp), row0, rows_end, n0, tid, wr, wc, frow, fk);
+        else wave_epilogue<EPI, 4, 2>(p, g, acc, row0 + wr * 128, rows_end, n0 + wc * 64, frow, fk);
+        return;
+    }
+    if (wr == 1) __builtin_amdgcn_s_barrier();     // stagger: group 1 runs one half-period behind group 0
+    int st = 0;
+    for (int t = 0; t < total; ++t) {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            // ---- L: refill the slot both groups have left, fetch this sub-stage's fragments, make sure stage t+1 is here
+            if (sub == 0) issue();
+            fload(st, sub);
+            if (sub == NSUB - 1) wait_vmcnt<(NST - 2) * LPT>();
+            __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): fragments in registers
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();          // X
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M: 16 MFMAs, the partner wave of this SIMD is in its L phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();          // Y
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st = st == NST - 1 ? 0 : st + 1;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two groups
+    wait_vmcnt<0>();                               // the dummy tail reloads must have landed before LDS becomes the staging slab
+    staged_epilogue<EPI, 4, 2, 4, 512>(p, g, acc, reinterpret_cast<float*>(ldsp), row0, rows_end, n0, tid, wr, wc, frow, fk);
+}
+
+// p8 variants (VB_GEMM_P8): ping-pong 1 = BK 32 x 5 stages, 2 = BK 32 x 4, 3 = BK 64 x 2; software-pipelined 4 / 5 / 6 = the same rings
+template <int EPI, int BKT, int NST, int PP, int ABL = 0, int STG = 1>
+static void launch_p8_v(const GemmDev& d, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)NST * 2 * 256 * BKT * 2;
+    static_assert(lds >= (size_t)256 * 68 * 4 && lds <= 160 * 1024, "LDS budget");
+    static OnceFlags attr;
+    if (vb_first_use_on_device(attr))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), grid, dim3(512), lds, st, d);
+}
+#ifndef P8_DEFAULT_BKT
+#define P8_DEFAULT_BKT 32
+#define P8_DEFAULT_NST 5
+#define P8_DEFAULT_PP 0
+#endif
+template <int EPI>
+static void launch_p8(const GemmDev& d, dim3 grid, hipStream_t st, int variant) {
+    if constexpr (EPI == EPI_F32) {      // the alternative schedules / ring shapes exist for the micro-benchmark only (tools/gemm_p8_bench.py)
+        if (variant == 1) { launch_p8_v<EPI, 32, 5, 1>(d, grid, st); return; }
+        if (variant == 2) { launch_p8_v<EPI, 32, 4, 1>(d, grid, st); return; }
+        if (variant == 3 && d.K % 64 == 0) { launch_p8_v<EPI, 64, 2, 1>(d, grid, st); return; }
+        if (variant == 4) { launch_p8_v<EPI, 32, 5, 0>(d, grid, st); return; }
+        if (variant == 5) { launch_p8_v<EPI, 32, 4, 0>(d, grid, st); return; }
+        if (variant == 6 && d.K % 64 == 0) { launch_p8_v<EPI, 64, 2, 0>(d, grid, st); return; }
+        if (variant == 11) { launch_p8_v<EPI, 32, 5, 0, 1>(d, grid, st); return; }       // ablations of the pipelined 32 x 5 ring
+        if (variant == 12) { launch_p8_v<EPI, 32, 5, 0, 2>(d, grid, st); return; }
+        if (variant == 13) { launch_p8_v<EPI, 32, 5, 0, 3>(d, grid, st); return; }
+        if (variant == 14) { launch_p8_v<EPI, 32, 5, 0, 4>(d, grid, st); return; }
+        if (variant == 15) { launch_p8_v<EPI, 32, 5, 0, 5>(d, grid, st); return; }
+    }
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU) {
+        if (vb_tune().gemm_p8_direct & (1 << EPI)) { launch_p8_v<EPI, P8_DEFAULT_BKT, P8_DEFAULT_NST, P8_DEFAULT_PP, 0, 0>(d, grid, st); return; }
+    }
+    launch_p8_v<EPI, P8_DEFAULT_BKT, P8_DEFAULT_NST, P8_DEFAULT_PP>(d, grid, st);
+}
+template <int EPI> struct P8Epi { static constexpr bool ok = EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_RESID_GATE ||
+                                                            EPI == EPI_SWIGLU || EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES; };
+
 template <int EPI, int TM, int TN, int NSTB>
 static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NSTB * (64 * TM + 64 * TN) * 128;
@@ -1124,7 +1417,27 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
         }
     }
-    const int bm = cfg ? 64 * (cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10) : BN;
+    // 8-wave 256 x 256 kernel (variant 4): taken when the problem makes enough of its tiles to occupy a good part of the chip - it
+    // moves half the bytes per flop through the L2 -> LDS feed, so it wins even at ~55 % of the CUs busy (12032 x 768: 141 tiles);
+    // small problems (one 20 s clip: 18 tiles) stay on the 128 x 128 kernel.  VB_GEMM_P8 = 0 off / 1..3 force a ring shape.
+    {
+        const int p8 = vb_tune().gemm_p8;
+        const bool epi_ok = a.epi == EPI_PLANES || a.epi == EPI_F32 || a.epi == EPI_QKV_ROPE || a.epi == EPI_RESID_GATE ||
+                            a.epi == EPI_SWIGLU || a.epi == EPI_SCATTER_F32 || a.epi == EPI_SCATTER_ADD_PLANES;
+        if (epi_ok && a.K % 32 == 0 && p8 != 0 && vb_tune().gemm_tile < 0) {
+            const int gz = a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
+            const int64_t t88 = (int64_t)(a.group_off ? (cdiv(a.M, 256) + a.ngroups) : cdiv(a.M, 256)) * cdiv(a.N, 256) * gz;
+            // measured (tools/gemm_p8_bench.py, profiles/r02_gemm_p8_microbench.txt): with one workgroup per CU nothing overlaps a
+            // tile's epilogue, so the 8-wave kernel only wins where the mainloop outweighs the output traffic - the wide
+            // projections (N >= 1024: QKV, routed w1/w3); the N = 768 / 640 launches stay on the two-per-CU 128 x 128 kernel
+            // and inside the DiT even those lose (A/B in the pipeline, profiles/r02_p8_pipeline_ab.txt: GEMM class 74 -> 86 ms per pass):
+            // QKV's RoPE / V-transpose epilogue and the gathered grouped SwiGLU cost more on a 256-row tile than the mainloop gains.
+            // The kernel therefore stays an opt-in (VB_GEMM_P8 >= 1) - kept for the micro-benchmark and as the record of the experiment.
+            if (p8 > 0) cfg = 88;
+            else if (p8 < 0 && (vb_tune().gemm_p8_mask & (1 << a.epi)) && t88 >= P8_MIN_TILES) cfg = 88;     // per-epilogue opt-in (A/B tool)
+        }
+    }
+    const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
@@ -1135,7 +1448,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
 #define VB_GEMM_CASE(E) \
         case E: \
-            if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
+            if (cfg == 88) { if constexpr (P8Epi<E>::ok) launch_p8<E>(d, grid, st, vb_tune().gemm_p8); } \
+            else if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
             else if (cfg == 24) launch_big<E, 2, 4, 3>(d, grid, st); \
             else if (cfg == 42) launch_big<E, 4, 2, 3>(d, grid, st); \
             else launch_t<E>(d, grid, st); \

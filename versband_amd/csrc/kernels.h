@@ -169,6 +169,7 @@ int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64
 int launch_rows_dot(const float* x, const float* W, const float* bias, int N, int D, int E, float* out, hipStream_t st);
 int launch_gn_stats(const float* x, int B, int C, int T, int groups, float eps, float* mean, float* rstd, hipStream_t st);
 int launch_softmax_rows_t(const float* s, int B, int R, int Ccols, float* out_t, hipStream_t st);
+int launch_sampler_params(int* step, uint64_t seed, int64_t clip_base, int nfe_base, hipStream_t st);   // step[4..9]: noise key of the call
 int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, int reset, hipStream_t st);
 int launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
 

@@ -80,6 +80,8 @@ class DiTEngine:
         self._ws_key = None
         self._checked: Dict[Tuple[int, int, int], bool] = {}     # (data_ptr, version, numel) of index tracks already range-checked
         self._tables: Dict[tuple, Tuple[Tensor, Tensor]] = {}    # device copies of the (t_idx, dt) step tables
+        self._pcond: Dict[tuple, list] = {}                      # persistent conditioning buffers: key -> [buffer, generation]
+        self._xbuf: Dict[tuple, Tensor] = {}                     # engine-owned sampler state (stable address for graph replay)
 
     # -- buffers -----------------------------------------------------------
     def _workspace(self, B, nb, T, Lc) -> Tensor:
@@ -91,8 +93,11 @@ class DiTEngine:
         return self._ws
 
     # -- API ---------------------------------------------------------------
-    def precompute_cond(self, t5: Tensor, midi: Tensor, beats: Tensor, T: int) -> dict:
-        """t5 [nb*B, L, ori] (cond rows then uncond rows), midi/beats [B,1,T_mel] or [B,T_mel] int64."""
+    def precompute_cond(self, t5: Tensor, midi: Tensor, beats: Tensor, T: int, persistent: bool = False) -> dict:
+        """t5 [nb*B, L, ori] (cond rows then uncond rows), midi/beats [B,1,T_mel] or [B,T_mel] int64.
+        persistent=True writes into an engine-owned buffer that the NEXT persistent precompute of the same shape overwrites (a
+        serving loop: precompute -> sample -> discard): stable device addresses are what lets vb_sample_cfg replay its captured
+        hipGraph.  A stale handle is refused loudly (generation check) instead of sampling from overwritten conditioning."""
         dev = self.ctx.device
         t5 = t5.to(dev, torch.float32).contiguous()
         midi = midi.to(dev, torch.int64).reshape(midi.shape[0], -1).contiguous()
@@ -112,11 +117,28 @@ class DiTEngine:
                 self._checked.clear()
             self._checked[key] = True
         n = self.ctx.lib.vb_dit_cond_bytes(C.byref(self.ccfg), B, nb, T, Lc)
-        cond = torch.empty(n, dtype=torch.uint8, device=dev)
+        gen = None
+        if persistent:
+            key = (B, nb, T, Lc)
+            slot = self._pcond.get(key)
+            if slot is None or slot[0].numel() != n:
+                slot = [torch.empty(n, dtype=torch.uint8, device=dev), 0]
+                self._pcond[key] = slot
+            slot[1] += 1
+            cond, gen = slot[0], slot[1]
+        else:
+            cond = torch.empty(n, dtype=torch.uint8, device=dev)
         ws = self._workspace(B, nb, T, Lc)
         L.check(self.ctx.lib.vb_dit_precompute_cond(self.ctx.handle, L.ptr(t5), L.ptr(midi), L.ptr(beats), B, nb, T, T_mel, Lc,
                                                     L.ptr(cond), L.ptr(ws), L.stream_ptr()), "vb_dit_precompute_cond")
-        return {"buf": cond, "B": B, "nb": nb, "T": T, "L": Lc}
+        return {"buf": cond, "B": B, "nb": nb, "T": T, "L": Lc, "gen": gen}
+
+    def _check_cond(self, cond: dict):
+        if cond.get("gen") is not None:
+            slot = self._pcond.get((cond["B"], cond["nb"], cond["T"], cond["L"]))
+            if slot is None or slot[1] != cond["gen"] or slot[0] is not cond["buf"]:
+                raise L.VersbandError("stale persistent conditioning handle: a later precompute_cond(persistent=True) of the same shape "
+                                      "overwrote this buffer")
 
     def _noise_struct(self, noise, seed, clip_base, nfe):
         ns = L.Noise()
@@ -134,6 +156,7 @@ class DiTEngine:
         draws or None -> v [nb*B, C, T] (+ routes int32 [depth,2,rows])."""
         dev = self.ctx.device
         B, nb, T, Lc = cond["B"], cond["nb"], cond["T"], cond["L"]
+        self._check_cond(cond)
         x = x.to(dev, torch.float32).contiguous()
         t_idx = t_idx.to(dev, torch.int64).contiguous()
         assert x.shape == (B, self.cfg.in_channels, T) and t_idx.numel() == nb * B
@@ -150,7 +173,13 @@ class DiTEngine:
         """n Euler steps with classifier-free guidance; x0 [B,C,T] is not modified."""
         dev = self.ctx.device
         B, nb, T, Lc = cond["B"], cond["nb"], cond["T"], cond["L"]
-        x = x0.to(dev, torch.float32).contiguous().clone()
+        self._check_cond(cond)
+        xkey = (B, self.cfg.in_channels, T)
+        assert tuple(x0.shape) == xkey, (tuple(x0.shape), xkey)
+        if xkey not in self._xbuf:
+            self._xbuf[xkey] = torch.empty(xkey, dtype=torch.float32, device=dev)
+        x = self._xbuf[xkey]            # the state the solver integrates in place; the caller gets a copy
+        x.copy_(x0.to(dev, torch.float32))
         n = len(t_idx_table)
         tkey = (tuple(int(v) for v in t_idx_table), tuple(float(v) for v in dt_table))
         if tkey not in self._tables:            # step tables live on the device: nothing on the host has to outlive the async launch
@@ -163,7 +192,12 @@ class DiTEngine:
         ws = self._workspace(B, nb, T, Lc)
         L.check(self.ctx.lib.vb_sample_cfg(self.ctx.handle, L.ptr(x), L.ptr(cond["buf"]), B, nb, T, Lc, n, L.ptr(tt), L.ptr(dd), float(scale),
                                            C.byref(ns), L.ptr(traj), L.ptr(ws), L.stream_ptr()), "vb_sample_cfg")
+        x = x.clone()
         return (x, traj) if return_traj else x
+
+    def graphs(self) -> int:
+        """instantiated hipGraphs of the sampler loop this engine's context holds (0 = every call ran eagerly)"""
+        return int(self.ctx.lib.vb_sample_graphs(self.ctx.handle))
 
 
 class T5Engine:

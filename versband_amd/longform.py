@@ -75,7 +75,7 @@ def sample_long(engine, x0: Tensor, t5_cond: Tensor, t5_uncond: Tensor, midi: Te
     mw = torch.cat([midi[:, 2 * s:2 * (s + n)] for s, _ in plan], dim=0)
     bw = torch.cat([beats[:, 2 * s:2 * (s + n)] for s, _ in plan], dim=0)
     t5 = torch.cat([t5_cond.repeat(nw, 1, 1), t5_uncond.repeat(nw, 1, 1)], dim=0)
-    cond = engine.precompute_cond(t5, mw, bw, n)
+    cond = engine.precompute_cond(t5, mw, bw, n, persistent=True)
     zw = engine.sample_cfg(xw, cond, t_idx_table, dt_table, scale, seed=seed, clip_base=clip_base * nw)
     parts = [zw[i * B:(i + 1) * B] for i in range(nw)]
     return crossfade_windows(parts, plan, T)
