@@ -39,8 +39,11 @@ GOLD = os.path.join(REPO, "tests", "golden")
 # ---------------------------------------------------------------------------
 
 def _mod(name, **attrs):
+    import importlib.machinery
     m = types.ModuleType(name)
     m.__vb_stub__ = True
+    # a real module spec: importlib.util.find_spec() (transformers probes optional packages with it) raises on __spec__ = None
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m
@@ -68,6 +71,9 @@ class _Euler:
 
 def install_stubs():
     import transformers  # noqa: F401  (must be imported before torchvision is stubbed)
+    # resolve transformers' lazily imported T5 classes NOW, before flash_attn / torchvision are replaced by stubs: their import
+    # chain probes those packages, so gen_t5() after install_stubs() used to fail unless it was run on its own
+    from transformers import T5Config, T5EncoderModel  # noqa: F401
     _mod("flash_attn", flash_attn_func=None, flash_attn_varlen_func=None)
     _mod("flash_attn.bert_padding", index_first_axis=None, pad_input=None, unpad_input=None)
 

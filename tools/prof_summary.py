@@ -5,7 +5,7 @@ import sys
 path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof/trace/bench_kernel_stats.csv"
 passes = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 24
-rows = list(csv.DictReader(open(path)))
+rows = list(csv.DictReader(l for l in open(path) if not l.startswith("#")))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel ms per pass {tot / passes / 1e6:.2f}")
 for r in rows[:top]:
