@@ -246,3 +246,25 @@ def test_cast_planes_roundtrip(lib):
     sync()
     assert torch.equal(out.cpu(), pack.to_planes(x, 2))       # bit-exact with the host packer (RNE both sides)
     assert rel_l2(pack.planes_to_float(out.cpu()), x) < 2e-5
+
+
+def test_staged_conv_epilogues_are_bit_identical(lib, monkeypatch):
+    """The split-bf16 conv kernel and the fused ResBlock-pair kernel pass their accumulator tiles through wave-private LDS patches
+    to move residual / output as 16-byte lane accesses when the rows are 16-B aligned (T % 4 == 0); VB_CONV_DIRECT_EPI=1 keeps the
+    4-byte direct epilogue.  Same arithmetic per element: the whole vocoder must come out bit for bit the same (also on a
+    length that is not a multiple of 4, where both take the direct path for the plain convs)."""
+    from versband_amd import synth
+    from versband_amd.engine import Context, build_hifigan
+    hcfg = synth.HifiGanConfig()
+    sdh = synth.make_state_dict(synth.hifigan_shapes(hcfg), 77)
+    net = build_hifigan(Context("cuda:0"), sdh, hcfg.as_hparams())
+    for T in (48, 37):
+        mel = torch.from_numpy(prng.uniform(prng.key_seed(9, f"mel{T}"), 2 * 80 * T, -5.0, 1.0).reshape(2, 80, T)).cuda()
+        a = net.run(mel).clone()
+        monkeypatch.setenv("VB_CONV_DIRECT_EPI", "1")
+        lib.vb_tune_reload()
+        b = net.run(mel).clone()
+        monkeypatch.delenv("VB_CONV_DIRECT_EPI")
+        lib.vb_tune_reload()
+        sync()
+        assert torch.isfinite(a).all() and torch.equal(a, b), f"T={T}: staged vs direct epilogue differ by {float((a - b).abs().max()):.3e}"

@@ -38,7 +38,76 @@ struct ConvDev {
     const bf16_t* wp; int64_t wp_plane; int Ci_pad;   // split-bf16 weights [2 planes][phase][tap][Co][Ci_pad]
     int64_t wp_bstride;
     const bf16_t* xt; int64_t xt_plane; int xt_Tp;     // pre-activated transposed split planes of the input (XT mode)
+    int stage_epi;           // [b][co][t] output, stride 1, T_out % 4 == 0, 16-B aligned rows: the staged (16-B lane) epilogue
 };
+
+// One output element of the [b][co][t] epilogues.  The arithmetic is pinned (no implicit contraction, one explicit fma): the direct
+// and the staged epilogue - and every tile configuration - must round alike, bit for bit.
+__device__ __forceinline__ float conv_out_value(const ConvDev& p, float acc, float bias, float res, float old) {
+#pragma clang fp contract(off)
+    float val = acc * p.acc_scale;
+    val = val + bias;
+    val = val + res;
+    if (p.out_act == ACT_LRELU) val = val > 0.f ? val : val * p.out_slope;
+    else if (p.out_act == ACT_TANH) val = tanhf(val);
+    return fmaf(val, p.alpha, p.beta * old);
+}
+
+// Staged variant of the [b][co][t] epilogue.  The MFMA accumulator gives a lane ONE output position and 16 channels, so the direct
+// epilogue below moves every residual / accumulate-into load and every store as 4-byte lane accesses (two 128-B row pieces per
+// wave instruction) - on the narrow, long vocoder layers that epilogue was half of the kernel (tools/conv_bench.py noEpi column:
+// 743 -> 367 us at 128 channels, 1075 -> 267 us at 32).  Here each wave passes its 32 x 32 tiles through a PRIVATE 4.5-KB LDS
+// patch (no block barrier: only the wave's own writes precede its reads) and comes back with a lane owning 4 consecutive
+// positions of one channel: residual, accumulate-into and output move as 16-byte lane accesses, 8 full 128-B lines per wave
+// instruction.  Same arithmetic per element, same order: bit-identical to the direct form.
+#define CE_PITCH 36          // floats per staged channel row (32 + 4: keeps the 16-B reads aligned, spreads the rows over banks)
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_staged(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
+                                                     float* stage) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    float* patch = stage + wave * (32 * CE_PITCH);
+    const int rr = lane >> 3, t4 = (lane & 7) * 4;           // read-back: channel row rr + 8k, positions t4 .. t4+3
+    float* ob = p.out + (int64_t)b * p.out_bstride;
+    const float* rb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int nb = n0 + (wn * TN + jn) * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int cb = co0 + (wm * TM + i) * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[(4 * g + 8 * (r >> 2) + (r & 3)) * CE_PITCH + l31] = acc[i][jn][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): own writes landed (wave-private patch)
+            float4 v[4], rv[4], ov[4];
+            float bv[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = cb + rr + 8 * k, n = nb + t4;
+                ok[k] = co < p.Co && n < n_count;            // (n_count % 4 == 0 is a launch condition of this variant)
+                v[k] = *reinterpret_cast<const float4*>(patch + (rr + 8 * k) * CE_PITCH + t4);
+                const int64_t oi = (int64_t)(ok[k] ? co : 0) * p.T_out + (ok[k] ? n : 0);
+                rv[k] = (ok[k] && rb) ? *reinterpret_cast<const float4*>(rb + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ov[k] = (ok[k] && p.beta != 0.f) ? *reinterpret_cast<const float4*>(ob + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[k] = (ok[k] && p.bias) ? p.bias[co] : 0.f;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // the patch is read before the next tile overwrites it
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!ok[k]) continue;
+                const int co = cb + rr + 8 * k, n = nb + t4;
+                const float a4[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+                const float o4[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
+                float q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = conv_out_value(p, a4[e], bv[k], r4[e], o4[e]);
+                *reinterpret_cast<float4*>(ob + (int64_t)co * p.T_out + n) = make_float4(q[0], q[1], q[2], q[3]);
+            }
+        }
+    }
+}
 
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
@@ -96,11 +165,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[TM
                 for (int r = 0; r < 16; ++r) {
                     const int co = cobase + 8 * (r >> 2) + (r & 3);
                     if (!nok || co >= p.Co) continue;
-                    float val = acc[i][jn][r] * p.acc_scale + bv[r] + rv[r];
-                    if (p.out_act == ACT_LRELU) val = val > 0.f ? val : val * p.out_slope;
-                    else if (p.out_act == ACT_TANH) val = tanhf(val);
-                    val = val * p.alpha + p.beta * ov[r];
-                    p.out[(int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t] = val;
+                    p.out[(int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t] = conv_out_value(p, acc[i][jn][r], bv[r], rv[r], ov[r]);
                 }
             }
         }
@@ -462,7 +527,10 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
             for (int jn = 0; jn < TN; ++jn) sink += acc[i][jn][0] + acc[i][jn][7];
         if (sink == 12345.678f) p.out[0] = sink;
     } else {
-        conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
+        // (the loop's last __syncthreads() is behind every wave: xT is free and holds the four wave-private staging patches)
+        static_assert(sizeof(xT) >= 4 * 32 * CE_PITCH * sizeof(float), "staging patches must fit in the window buffer");
+        if (p.stage_epi) conv_epilogue_staged<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, reinterpret_cast<float*>(&xT[0][0]));
+        else conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
     }
 }
 
@@ -497,6 +565,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     d.xt = a.xt; d.xt_Tp = xt_rows(a.upsample2 ? 2 * a.T_in : a.T_in); d.xt_plane = (int64_t)a.B * d.xt_Tp * a.Ci;
     if (a.xt && (a.Ci % CK3 || a.tr_stride > 1 || a.in_stride > 1 || !a.wp || a.x_bmod || a.pad > XT_HEAD))
         VB_FAIL(VB_E_INVALID, "conv1d: XT input needs Ci %% 32 == 0, stride 1, split weights, pad <= %d", XT_HEAD);
+    d.stage_epi = 0;
     int n_count;
     if (a.tr_stride > 1) {
         d.phases = a.tr_stride; d.tr_pad = a.tr_pad; d.ntaps = (a.tr_k + a.tr_stride - 1) / a.tr_stride; d.dil = 1;
@@ -512,6 +581,10 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * taps_eff,
                    4.0 * a.B * ((double)a.Ci * a.T_in * (a.xt ? 1.0 : 1.0) + (double)a.Co * a.T_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.beta != 0.f ? 1.0 : 0.0)))
                        + 4.0 * (double)a.Co * a.Ci * (a.tr_stride > 1 ? a.tr_k : a.ksize), st);
+    // staged epilogue (split-bf16 kernel): plain [b][co][t] output whose rows start 16-B aligned
+    d.stage_epi = (a.tr_stride <= 1 && !a.out_transposed && a.T_out % 4 == 0 && a.out_bstride % 4 == 0 &&
+                   (!a.res || a.res_bstride % 4 == 0) && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                   (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) && !vb_tune().conv_direct_epi) ? 1 : 0;
     if (a.wp && (!a.w_bstride || a.wp_bstride)) {
         if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
         // VB_CONV_CFG (tuning knob): 1 = wide-T tile (64co x 256t) for 32 < Co <= 64

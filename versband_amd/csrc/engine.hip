@@ -26,6 +26,7 @@ static void tune_load() {
     t.gemm_p8_mask = env_int("VB_GEMM_P8_MASK", 0); t.gemm_p8_direct = env_int("VB_GEMM_P8_DIRECT", 0);
     t.conv_cfg = env_int("VB_CONV_CFG", 0); t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
     t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
+    t.conv_direct_epi = getenv("VB_CONV_DIRECT_EPI") != nullptr;
     t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
     t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr; t.moe_unfused = getenv("VB_MOE_UNFUSED") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;

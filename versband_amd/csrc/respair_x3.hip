@@ -25,7 +25,16 @@ struct PairDev {
     const bf16_t* w1; const bf16_t* w2; int64_t w_plane;      // [2 planes][k][C][C] each, ci contiguous
     const float* b1; const float* b2;
     float slope, alpha, beta;
+    int staged;               // 16-B (staged) epilogue: T % 4 == 0 and 16-B aligned tensors
 };
+
+// one output element (pinned arithmetic: the direct and the staged epilogue must round alike)
+__device__ __forceinline__ float pair_out_value(const PairDev& p, float acc, float bias, float res, float old) {
+#pragma clang fp contract(off)
+    float val = acc + bias;
+    val = val + res;
+    return fmaf(val, p.alpha, p.beta * old);
+}
 
 template <int CH>      // C = 32*CH channels
 __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
@@ -43,7 +52,7 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
     const int g = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z;
     const int h2 = (p.k - 1) / 2, h1 = (p.k - 1) * p.dil / 2;
-    const int TT = RP_T - (p.k - 1);                 // outputs per workgroup
+    const int TT = (RP_T - (p.k - 1)) & ~3;          // outputs per workgroup (a multiple of 4: the epilogue moves 16-B quads)
     const int n0 = blockIdx.x * TT;                  // first output sample
     const int m0 = n0 - h2;                          // first intermediate position
     const int x0 = m0 - h1;                          // first window sample
@@ -199,8 +208,51 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
         taps(p.w2, ch * 32, &hT[ch][0][0], &hT[ch][1][0], 1);
     }
     fold_acc();
-    // ---- epilogue: lane owns output sample n (32 consecutive samples per co row across the half-wave)
-    {
+    // ---- epilogue.  The accumulator gives a lane ONE output sample and 16 channels; moved like that every residual /
+    // accumulate-into load and every store is a 4-byte lane access.  When the rows are 16-B aligned (T % 4 == 0) each wave passes
+    // its 32 x 32 tiles through a private LDS patch instead (xh is free: conv2's last barrier is behind every wave) and comes
+    // back with 4 consecutive samples of one channel per lane - 16-byte accesses, whole 128-B lines per 8 lanes; same
+    // arithmetic per element (see conv_epilogue_staged in conv1d_f32.hip).
+    constexpr int EP = 36;
+    static_assert(sizeof(xh) >= 4 * 32 * EP * sizeof(float), "staging patches must fit");
+    if (p.staged) {
+        float* patch = reinterpret_cast<float*>(xh) + wave * (32 * EP);
+        const int rr = lane >> 3, t4 = (lane & 7) * 4;
+        const int nl = 32 * wave + t4;
+        const int n = n0 + nl;
+        const bool nok = nl < TT && n < p.T;
+        float* ob = p.out + (int64_t)b * p.bstride;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[(4 * g + 8 * (r >> 2) + (r & 3)) * EP + l31] = acc[i][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            float4 v[4], rv[4], ov[4];
+            float bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = i * 32 + rr + 8 * k;
+                v[k] = *reinterpret_cast<const float4*>(patch + (rr + 8 * k) * EP + t4);
+                const int64_t oi = (int64_t)co * p.T + (nok ? n : 0);
+                rv[k] = nok ? *reinterpret_cast<const float4*>(xb + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ov[k] = (nok && p.beta != 0.f) ? *reinterpret_cast<const float4*>(ob + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[k] = p.b2[co];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (nok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int co = i * 32 + rr + 8 * k;
+                    const float a4[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
+                    const float o4[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
+                    float q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) q[e] = pair_out_value(p, a4[e], bv[k], r4[e], o4[e]);
+                    *reinterpret_cast<float4*>(ob + (int64_t)co * p.T + n) = make_float4(q[0], q[1], q[2], q[3]);
+                }
+            }
+        }
+    } else {
         const int nl = 32 * wave + l31;
         const int n = n0 + nl;
         const bool nok = nl < TT && n < p.T;
@@ -219,9 +271,7 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
             for (int r = 0; r < 16; ++r) {
                 const int co = i * 32 + 4 * g + 8 * (r >> 2) + (r & 3);
                 if (!nok) continue;
-                float val = acc[i][r] + bv[r] + rv[r];
-                val = val * p.alpha + p.beta * ov[r];
-                ob[(int64_t)co * p.T + n] = val;
+                ob[(int64_t)co * p.T + n] = pair_out_value(p, acc[i][r], bv[r], rv[r], ov[r]);
             }
         }
     }
@@ -236,7 +286,9 @@ int launch_respair(const RespairArgs& a, hipStream_t st) {
     d.x = a.x; d.out = a.out; d.bstride = (int64_t)a.C * a.T; d.T = a.T; d.k = a.k; d.dil = a.dil;
     d.w1 = a.w1; d.w2 = a.w2; d.w_plane = (int64_t)a.k * a.C * a.C; d.b1 = a.b1; d.b2 = a.b2;
     d.slope = a.slope; d.alpha = a.alpha; d.beta = a.beta;
-    const int TT = RP_T - (a.k - 1);
+    const int TT = (RP_T - (a.k - 1)) & ~3;
+    d.staged = (a.T % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                !vb_tune().conv_direct_epi) ? 1 : 0;
     dim3 grid(cdiv(a.T, TT), 1, a.B);
     // two convolutions' worth of flops (the recomputed halo of conv1 is not counted)
     ProfScope prof(3, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T,
