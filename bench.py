@@ -88,6 +88,68 @@ def pmc_traffic(cls):
         return None, None
 
 
+class Telemetry:
+    """shader clock / power of the AMD GPUs on this box, read from sysfs by a side thread WHILE the timed region runs (an idle
+    reading says nothing).  Boxes of this pool differ by ~17 % on the clock-bound kernels (attention, band experts, GEMMs) while the
+    memory-bound ones agree: the clock the timed region ran at belongs next to its throughput.  Best effort: {} when sysfs is absent."""
+
+    def __init__(self, period=0.03):
+        import glob
+        import threading
+        self.cards = [d for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+        self.samples, self.stop, self.period = [], False, period
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except Exception:
+            return ""
+
+    def _sample(self):
+        import glob
+        out = []
+        for d in self.cards:
+            cur = [ln for ln in self._read(os.path.join(d, "pp_dpm_sclk")).splitlines() if "*" in ln]
+            mhz = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit())) if cur else None
+            pw, cap = None, None
+            for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                a, c = self._read(os.path.join(h, "power1_average")) or self._read(os.path.join(h, "power1_input")), self._read(os.path.join(h, "power1_cap"))
+                pw = int(a) / 1e6 if a.strip().isdigit() else pw
+                cap = int(c) / 1e6 if c.strip().isdigit() else cap
+            out.append((mhz, pw, cap))
+        return out
+
+    def _run(self):
+        while not self.stop:
+            self.samples.append(self._sample())
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.cards:
+            self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.cards:
+            self.thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return {}
+        res = {}
+        for ci, d in enumerate(self.cards):
+            mhz = [s[ci][0] for s in self.samples if s[ci][0]]
+            pw = [s[ci][1] for s in self.samples if s[ci][1]]
+            cap = [s[ci][2] for s in self.samples if s[ci][2]]
+            res[d.split("/")[4]] = {"sclk_mhz_min": min(mhz) if mhz else None, "sclk_mhz_max": max(mhz) if mhz else None,
+                                    "power_w_avg": round(sum(pw) / len(pw), 1) if pw else None, "power_cap_w": cap[0] if cap else None,
+                                    "samples": len(self.samples)}
+        return res
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,10 +485,11 @@ def main():
     log(f"warmup done; dominant class = {CLASSES[dominant][0]}; timing {args.steps} step(s)")
 
     barrier()
-    t0 = time.perf_counter()
-    run_passes(list(range(args.steps)))
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with Telemetry() as tele:
+        t0 = time.perf_counter()
+        run_passes(list(range(args.steps)))
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -477,6 +540,7 @@ def main():
                        if any(w["eng"].graphs() for w in workers) else "eager launches",
                        "streams_per_gpu": S, "parallelism": f"batch-shard x{world} ({S} concurrent sub-batches of {Bs} clips per GPU)"},
             "parity_check": parity,
+            "device": {"name": torch.cuda.get_device_name(device), "clocks_during_timed_region": tele.summary()},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "how": ("dominant class = largest GPU time per pass; achieved = algorithmic flops of its event-timed launches / their "
                                  "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 5th "
