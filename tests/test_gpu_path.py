@@ -276,6 +276,19 @@ def test_sampler_graph_replay_equals_eager(ctx, sds, monkeypatch):
             outs[(seed, rep)] = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=seed, clip_base=rep)
         stream.synchronize()
         assert eng.graphs() == 1, "the repeated call was not captured"
+        # another engine of another shape runs, is destroyed and its memory returned to the driver between capture and replay (this
+        # sequence exposed a hipMemsetAsync node of the captured loop going wrong on ROCm 7.2: the loop now has kernel nodes only)
+        other = DiTEngine(ctx, synth.DiTConfig(), sds[4], precision="bf16", share=eng)
+        big = clip_batch(5, 200, Lc)
+        other.sample_cfg(big["x_latent"], other.precompute_cond(torch.cat([big["t5_cond"], big["t5_uncond"]]), big["midi"], big["beats"], 200),
+                         idx, dts, 3.0, seed=1)
+        stream.synchronize()
+        del other, big
+        torch.cuda.empty_cache()
+        cond = eng.precompute_cond(t5, midi, beats, T, persistent=True)
+        again = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=13, clip_base=3)
+        stream.synchronize()
+        assert torch.equal(again, outs[(13, 3)]) and torch.isfinite(again).all()
         stale = cond
         eng.precompute_cond(t5, midi, beats, T, persistent=True)
         with pytest.raises(VersbandError):

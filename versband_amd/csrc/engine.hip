@@ -721,7 +721,8 @@ static int sample_steps(vb_ctx* ctx, float* x, const void* cond, int B, int n_br
     WsL s = carve_ws(ws, c, B, n_branch, T, L);
     const int Beff = B * n_branch;
     const int64_t per = (int64_t)c.in_channels * T;
-    VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * c.np * sizeof(bf16_t), st));
+    // (a kernel, not hipMemsetAsync: the captured step loop then consists of kernel nodes only)
+    VB_TRY(launch_fill_f32(reinterpret_cast<float*>(s.vt), (int64_t)s.n_vt * c.np / 2, 0.f, st));
     // The timestep embedding, every block's adaLN modulation and the high-level gate logits depend on (t_k, caption)
     // only: tabulate them for ALL steps in four launches instead of four GEMVs inside every network evaluation.
     const bool tab = n_steps <= PRE_STEPS;
