@@ -344,12 +344,12 @@ __device__ __forceinline__ float reduce_logits(const float (&part)[16], int lane
 //   lc = cq . Wg^T + bg ; ic = argmax(lc + G2) ; ia = argmax(la + G3) (first maximum wins, like
 //   torch.max) ; (m_c, m_a) = softmax(hl[b] + G1).   G* are Gumbel draws (-log Exp(1)).
 // ---------------------------------------------------------------------------
-#define RT_TPW 4      // tokens per wave
+#define RT_TPW_MAX 4  // tokens per wave (4 when the launch fills the chip anyway; 1 for small batches: 4x the waves, a quarter of the latency)
 // SC = true: "folded" caption gate.  The token features are not materialised at all: `sc` holds the token's attention
 // SCORES against its clip's caption keys for all heads ([N][NS], NS = L * Hh, column = key * Hh + head; scale, q-projection
 // and q-bias already inside - one grouped GEMM against per-clip folded keys), `Wg` holds per clip VW[key*Hh+head][e] =
 // value_row(head) . (gate weight row e restricted to the head), so   logit_e = sum_heads sum_keys softmax(scores)_key VW_e.
-template <int PP, bool SC>     // PP: tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, else 1
+template <int PP, bool SC, int RT_TPW = RT_TPW_MAX>     // PP: tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, 2 when <= 32
 __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __restrict__ Wg,
                                                     const float* __restrict__ bg, const float* __restrict__ la, int la_rows,
                                                     const float* __restrict__ hl, int hl_ld, const float* __restrict__ g1,
@@ -404,6 +404,20 @@ __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __r
                         acc.x += sv[tok][i] * w.x; acc.y += sv[tok][i] * w.y; acc.z += sv[tok][i] * w.z; acc.w += sv[tok][i] * w.w;
                     }
                 parts[tok][0] = acc.x * inv; parts[tok][1] = acc.y * inv; parts[tok][2] = acc.z * inv; parts[tok][3] = acc.w * inv;
+            } else if (E == 8) {
+                // two 16-byte loads per (lane, key column) instead of eight 4-byte loads 32 B apart (8 experts, 48128 tokens: this loop
+                // was 469 us of a block evaluation, profiles/r02_c3_kernel_stats.csv)
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < kpl) {
+                        const float4 w0 = *reinterpret_cast<const float4*>(vwb + (int64_t)64 * i * 8);
+                        const float4 w1 = *reinterpret_cast<const float4*>(vwb + (int64_t)64 * i * 8 + 4);
+                        a0.x += sv[tok][i] * w0.x; a0.y += sv[tok][i] * w0.y; a0.z += sv[tok][i] * w0.z; a0.w += sv[tok][i] * w0.w;
+                        a1.x += sv[tok][i] * w1.x; a1.y += sv[tok][i] * w1.y; a1.z += sv[tok][i] * w1.z; a1.w += sv[tok][i] * w1.w;
+                    }
+                parts[tok][0] = a0.x * inv; parts[tok][1] = a0.y * inv; parts[tok][2] = a0.z * inv; parts[tok][3] = a0.w * inv;
+                parts[tok][4] = a1.x * inv; parts[tok][5] = a1.y * inv; parts[tok][6] = a1.z * inv; parts[tok][7] = a1.w * inv;
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -536,31 +550,42 @@ __global__ void __launch_bounds__(256) router_kernel(Planes cq, const float* __r
         }
     }
 }
+template <int PP, bool SC, int TPW>
+static void launch_router_v(dim3 grid, size_t lds, hipStream_t st, Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows,
+                            const float* hl, int hl_ld, const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic,
+                            int* ia, float* mc, float* ma, float* lc_out, int Bq, uint64_t seed, int64_t clip_base, int nfe_base,
+                            const int* step, int block, const float* sc, int NS, int Hh) {
+    hipLaunchKernelGGL((router_kernel<PP, SC, TPW>), grid, dim3(256), lds, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E,
+                       ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, sc, NS, Hh);
+}
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
                   hipStream_t st, const float* sc, int NS, int Hh) {
-    const dim3 grid(cdiv(N, 4 * RT_TPW));
     const int Bq = B > 0 ? B : 1;
+    // tokens per wave: 4 amortise the noise generator and the arg-max over a wave; a launch that would not even put one workgroup on
+    // every CU that way (one or two clips) takes one token per wave instead - the kernel is pure latency there (29 us at 1504 tokens)
+    const bool small = cdiv(N, 4 * RT_TPW_MAX) < 256;
+    const dim3 grid(cdiv(N, 4 * (small ? 1 : RT_TPW_MAX)));
+    const int pp = 2 * E + 2 <= 16 ? 4 : (2 * E + 2 <= 32 ? 2 : 1);
+#define VB_ROUTER_ARGS cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block
     if (sc) {
         // folded caption gate: logits from attention scores + per-clip VW (see router_kernel)
         if (NS % 64 || NS > 1024 || Hh < 1 || Hh > 64 || (Hh & (Hh - 1))) VB_FAIL(VB_E_INVALID, "router: NS=%d heads=%d unsupported", NS, Hh);
-        if (2 * E + 2 <= 16)
-            hipLaunchKernelGGL((router_kernel<4, true>), grid, dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E,
-                               ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, sc, NS, Hh);
-        else
-            hipLaunchKernelGGL((router_kernel<1, true>), grid, dim3(256), 0, st, cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E,
-                               ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, sc, NS, Hh);
+        if (small) launch_router_v<1, true, 1>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
+        else if (pp == 4) launch_router_v<4, true, 4>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
+        else if (pp == 2) launch_router_v<2, true, 4>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
+        else launch_router_v<1, true, 4>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
         VB_CHECK_LAUNCH();
         return VB_OK;
     }
     if ((E * D) % 4 != 0 || (size_t)E * D * sizeof(float) > 64 * 1024) VB_FAIL(VB_E_INVALID, "router: E*D=%d unsupported", E * D);
-    if (2 * E + 2 <= 16)
-        hipLaunchKernelGGL((router_kernel<4, false>), grid, dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
-                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, nullptr, 0, 1);
-    else
-        hipLaunchKernelGGL((router_kernel<1, false>), grid, dim3(256), (size_t)E * D * sizeof(float), st, cq, Wg, bg, la, la_mod_rows,
-                           hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block, nullptr, 0, 1);
+    const size_t lds = (size_t)E * D * sizeof(float);
+    if (small) launch_router_v<1, false, 1>(grid, lds, st, VB_ROUTER_ARGS, nullptr, 0, 1);
+    else if (pp == 4) launch_router_v<4, false, 4>(grid, lds, st, VB_ROUTER_ARGS, nullptr, 0, 1);
+    else if (pp == 2) launch_router_v<2, false, 4>(grid, lds, st, VB_ROUTER_ARGS, nullptr, 0, 1);
+    else launch_router_v<1, false, 4>(grid, lds, st, VB_ROUTER_ARGS, nullptr, 0, 1);
+#undef VB_ROUTER_ARGS
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

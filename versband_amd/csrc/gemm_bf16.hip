@@ -1152,6 +1152,7 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
         if (abl == 5 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 5>), grid, dim3(NTHREADS), 0, st, d); return; }
     }
     if (variant == 1 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2>), grid, dim3(NTHREADS), 0, st, d);
+    else if (variant == 1 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);   // K = 96 bands (8 experts)
     else if (variant == 2 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);
     else if (variant == 3 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d);
     else if (variant == 4 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d);
@@ -1415,6 +1416,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             const int64_t t33 = rt * cdiv(a.N, 192) * gz;
             const int64_t t22 = (a.group_off ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
             if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
+            // small problems (one or two clips): 128x128 tiles leave most CUs idle and a tile's 12 k-iterations are pure DMA latency;
+            // 64x64 tiles (three workgroups per CU) make 4x the tiles.  VB_GEMM_SMALL=0 keeps the 128x128 kernel, 21 takes 128x64.
+            else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles) cfg = vb_tune().gemm_small;
         }
     }
     // 8-wave 256 x 256 kernel (variant 4): taken when the problem makes enough of its tiles to occupy a good part of the chip - it
@@ -1452,6 +1456,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             else if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
             else if (cfg == 24) launch_big<E, 2, 4, 3>(d, grid, st); \
             else if (cfg == 42) launch_big<E, 4, 2, 3>(d, grid, st); \
+            else if (cfg == 11) launch_big<E, 1, 1, 3>(d, grid, st); \
+            else if (cfg == 21) launch_big<E, 2, 1, 3>(d, grid, st); \
             else launch_t<E>(d, grid, st); \
             break;
     switch (a.epi) {
