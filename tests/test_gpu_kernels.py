@@ -148,6 +148,55 @@ def test_attention(lib, B, T, Lc, H, cross, self_, npl):
     assert rel_l2(got, ref) < tol, describe(f"attention np={npl}", got, ref)
 
 
+@pytest.mark.parametrize("npl", [1, 2])
+def test_attention_deferred_rescale_on_spiked_keys(lib, npl, monkeypatch):
+    """The kernel moves its running row maximum only when a row outgrows it by 2^thr (VB_ATTN_DEFER, log2 units).  Keys that
+    dwarf everything seen before - late in the sequence, for a few rows only, in the middle of a 64-key tile - force that
+    rare branch; thr = 0 (exact running maximum), the default and "never again after the first tile" (thr = 1e9) must all
+    agree with the float64 reference, and the default with thr = 0 to rounding."""
+    B, T, H, hd, Lc = 1, 400, 2, 96, 20
+    q, k, v = rnd((B, T, H, hd), "dq"), rnd((B, T, H, hd), "dk"), rnd((B, T, H, hd), "dv")
+    ky, vy, cw = rnd((B, Lc, H, hd), "dky"), rnd((B, Lc, H, hd), "dvy"), rnd((H,), "dcw")
+    for row, key, gain in ((7, 150, 30.0), (7, 333, 60.0), (200, 390, 45.0), (399, 70, 25.0)):
+        k[0, key] = q[0, row] * gain / q[0, row].pow(2).sum(-1, keepdim=True).sqrt()     # q_row . k_key ~ gain * |q_row|: scores far above the rest
+    Tpad, Lpad = (T + 63) // 64 * 64, 64
+
+    def vt_layout(x, S, Spad):
+        o = torch.zeros(B, H, hd, Spad)
+        o[..., :S] = x.permute(0, 2, 3, 1)
+        return o
+    qp, kp, vtp = dev(pack.to_planes(q, npl)), dev(pack.to_planes(k, npl)), dev(pack.to_planes(vt_layout(v, T, Tpad), npl))
+    kyp, vytp = dev(pack.to_planes(ky, npl)), dev(pack.to_planes(vt_layout(vy, Lc, Lpad), npl))
+    src = (lambda t, pl: pack.planes_to_float(pl.cpu()).reshape(t.shape)) if npl == 1 else (lambda t, pl: t)
+    qq, kk, kyy = src(q, qp).double(), src(k, kp).double(), src(ky, kyp).double()
+    vv, vyy = (v.to(torch.bfloat16).double(), vy.to(torch.bfloat16).double()) if npl == 1 else (v.double(), vy.double())
+    ref = ref_cpu.sdpa(qq.permute(0, 2, 1, 3), kk.permute(0, 2, 1, 3), vv.permute(0, 2, 1, 3)) \
+        + ref_cpu.sdpa(qq.permute(0, 2, 1, 3), kyy.permute(0, 2, 1, 3), vyy.permute(0, 2, 1, 3)) * cw.double().view(1, H, 1, 1)
+    ref = ref.permute(0, 2, 1, 3)
+    outs = {}
+    for thr in ("0", None, "1e9"):
+        if thr is None:
+            monkeypatch.delenv("VB_ATTN_DEFER", raising=False)
+        else:
+            monkeypatch.setenv("VB_ATTN_DEFER", thr)
+        lib.vb_tune_reload()
+        out = torch.zeros(npl, B, T, H, hd, dtype=torch.bfloat16, device="cuda")
+        L.check(lib.vb_attention(L.ptr(qp), L.ptr(kp), L.ptr(vtp), L.ptr(kyp), L.ptr(vytp), L.ptr(dev(cw)), B, T, Tpad, Lc, Lpad, H, hd, npl,
+                                 L.ptr(out), L.stream_ptr()), "attention")
+        sync()
+        outs[thr] = pack.planes_to_float(out.cpu())
+        assert torch.isfinite(outs[thr]).all()
+        tol = 6e-3 if npl == 1 else 4e-5
+        if thr != "1e9":         # (never rescaling after the first tile loses the small rows' precision by construction: finite, not accurate)
+            assert rel_l2(outs[thr], ref) < tol, describe(f"attention defer={thr} np={npl}", outs[thr], ref)
+            # the spiked rows themselves (a relative norm over the whole tensor would hide four bad rows)
+            for row in (7, 200, 399):
+                assert rel_l2(outs[thr][0, row], ref[0, row]) < tol, describe(f"row {row} defer={thr}", outs[thr][0, row], ref[0, row])
+    monkeypatch.delenv("VB_ATTN_DEFER", raising=False)
+    lib.vb_tune_reload()
+    assert rel_l2(outs[None], outs["0"]) < (4e-3 if npl == 1 else 2e-5)
+
+
 # ---------------------------------------------------------------- small kernels ------
 @pytest.mark.parametrize("npl", [1, 2])
 def test_rmsnorm_modulate(lib, npl):

@@ -32,7 +32,7 @@ struct AttnDev {
     bf16_t* out; int64_t out_plane; int out_np;
     int B, T, Tpad, L, Lpad, H, D;
     int has_self, has_cross, kv_batch_mod, nq;
-    float scale_log2e;
+    float scale_log2e, defer_thr;
 };
 
 // ABL (tuning only): 1 = no K/V tile traffic in the loop, 2 = no softmax math, 3 = no P.V MFMAs, 4 = no Q.K^T MFMAs
@@ -122,12 +122,32 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
             if constexpr (!SPLIT) {
                 if (ABL != 1 && kt + 1 < ntiles) tile_load(kt + 1, kreg, vreg, 0);
             }
-            // ---- S^T = K Q^T  (two 32-key sub-tiles)
+            // ---- S^T = K Q^T  (two 32-key sub-tiles, two independent accumulator chains; the K fragments of k-step ks+1 are requested
+            // before the MFMAs of ks are queued - the plain loop waited out an LDS round trip in front of every pair of MFMAs)
             f32x16 s[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            if constexpr (!SPLIT && ABL != 4) {
+                bf16x8 kfr[2][2];
+                auto krd = [&](int ks, int slot) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+                        kfr[slot][kb] = *reinterpret_cast<const bf16x8*>(&Kl[0][(kb * 32 + ql) * KPITCH + ks * 16 + g * 8]);
+                };
+                krd(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) {
+                    if (ks + 1 < 6) krd(ks + 1, (ks + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks & 1][kb], qf[ks], s[kb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) {
                     const int off = (kb * 32 + ql) * KPITCH + ks * 16 + g * 8;
@@ -140,6 +160,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qlf[ks], s[kb], 0, 0, 0);
                     }
                 }
+            }
             }
             if constexpr (ABL != 2) {
             // ---- online softmax (base-2 domain).  Lean VALU path: the key mask is applied only on a partial tile,
@@ -162,7 +183,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_run, tmax * p.scale_log2e);     // every tile holds >= 1 valid key: finite
-            if (!__all(m_new == m_run)) {
+            // deferred rescale: the running maximum (and with it the 48 accumulator registers) is only moved when some row of the wave
+            // outgrew it by more than 2^thr - until then P = exp2(s - m_run) <= 2^thr, harmless in fp32 sums and relative in bf16.
+            // thr = 0 is the exact running maximum.  The decision depends on this wave's 32 query rows only (not on the batch).
+            if (!__all(m_new <= m_run + p.defer_thr)) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 m_run = m_new;
                 l_run *= alpha;
@@ -275,6 +299,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
     d.B = a.B; d.T = a.T; d.Tpad = a.Tpad; d.L = a.L; d.Lpad = a.Lpad; d.H = a.H; d.D = a.H * a.hd;
     d.has_self = a.has_self; d.has_cross = a.has_cross; d.kv_batch_mod = a.kv_batch_mod;
     d.scale_log2e = a.scale * 1.4426950408889634f;
+    d.defer_thr = vb_tune().attn_defer_thr;
     const double ae = (double)a.B * a.H * a.hd * 2.0 * a.q.np;      // bytes per token (or key) row of one q/k/v/out tensor
     ProfScope prof(1, 4.0 * a.B * a.H * a.T * a.hd * ((a.has_self ? a.T : 0) + (a.has_cross ? a.L : 0)),
                    ae * (2.0 * a.T + (a.has_self ? 2.0 * a.T : 0) + (a.has_cross ? 2.0 * a.L : 0)), st);

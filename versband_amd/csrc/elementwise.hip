@@ -565,14 +565,17 @@ int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, 
     const int Bq = B > 0 ? B : 1;
     // tokens per wave: 4 amortise the noise generator and the arg-max over a wave; a launch that would not even put one workgroup on
     // every CU that way (one or two clips) takes one token per wave instead - the kernel is pure latency there (29 us at 1504 tokens)
-    const bool small = cdiv(N, 4 * RT_TPW_MAX) < 256;
-    const dim3 grid(cdiv(N, 4 * (small ? 1 : RT_TPW_MAX)));
+    const int forced = vb_tune().router_tpw;                  // VB_ROUTER_TPW=1|2|4 (tuning)
+    const bool small = forced ? forced == 1 : cdiv(N, 4 * RT_TPW_MAX) < 256;
+    const bool two = forced == 2 && 2 * E + 2 <= 32;
+    const dim3 grid(cdiv(N, 4 * (small ? 1 : (two ? 2 : RT_TPW_MAX))));
     const int pp = 2 * E + 2 <= 16 ? 4 : (2 * E + 2 <= 32 ? 2 : 1);
 #define VB_ROUTER_ARGS cq, Wg, bg, la, la_mod_rows, hl, hl_ld, g1, g2, g3, N, T, D, E, ic, ia, mc, ma, lc_out, Bq, seed, clip_base, nfe_base, step, block
     if (sc) {
         // folded caption gate: logits from attention scores + per-clip VW (see router_kernel)
         if (NS % 64 || NS > 1024 || Hh < 1 || Hh > 64 || (Hh & (Hh - 1))) VB_FAIL(VB_E_INVALID, "router: NS=%d heads=%d unsupported", NS, Hh);
         if (small) launch_router_v<1, true, 1>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
+        else if (two) launch_router_v<2, true, 2>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
         else if (pp == 4) launch_router_v<4, true, 4>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
         else if (pp == 2) launch_router_v<2, true, 4>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);
         else launch_router_v<1, true, 4>(grid, 0, st, VB_ROUTER_ARGS, sc, NS, Hh);

@@ -21,6 +21,8 @@ static std::mutex g_tune_mu;
 static int env_int(const char* k, int dflt) { const char* v = getenv(k); return (v && *v) ? atoi(v) : dflt; }
 static void tune_load() {
     VbTune t;
+    t.router_tpw = env_int("VB_ROUTER_TPW", 0);
+    if (const char* v = getenv("VB_ATTN_DEFER")) t.attn_defer_thr = (float)atof(v);     // log2 units; 0 = exact running maximum
     t.gemm_small = env_int("VB_GEMM_SMALL", 11); t.gemm_small_tiles = env_int("VB_GEMM_SMALL_TILES", 300);
     t.gemm_tile = env_int("VB_GEMM_TILE", -1); t.gemm_variant = env_int("VB_GEMM_VARIANT", 1); t.gemm_ablate = env_int("VB_GEMM_ABLATE", 0);
     t.gemm_nchunk = env_int("VB_GEMM_NCHUNK", 0); t.gemm_p8 = env_int("VB_GEMM_P8", -1);

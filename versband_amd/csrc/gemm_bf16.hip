@@ -42,6 +42,7 @@ struct GemmDev {
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
     float rT, rhd, rD;              // reciprocals for fdiv(): the epilogues decompose row -> (clip, t) and column -> (head, d)
     unsigned long long* trace;      // tuning only (vbdbg_gemm_trace): per block {t_start, t_loop_end, t_end, hw ids}
+    int abl;                        // tuning only (VB_GEMM_ABLATE): 6 = QKV without the V^T stores, 7 = without the q/k stores, 8 = without the RoPE table loads
 };
 
 // x / d for 0 <= x < 2^21 without the ~40-instruction integer division: (x + 0.5) / d is at least 0.5/d away
@@ -85,7 +86,7 @@ __device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok
     } else if constexpr (EPI == EPI_SCATTER_ADD_PLANES) {
         e.a = *reinterpret_cast<const float4*>(p.y32_in + (int64_t)tok * p.ldc32 + n);
     } else if constexpr (EPI == EPI_QKV_ROPE) {
-        if (n < 2 * p.D) {
+        if (n < 2 * p.D && p.abl != 8) {
             const int nn = n - fdiv(n, p.rD) * p.D, t = m - fdiv(m, p.rT) * p.T;
             const int jd = (nn - fdiv(nn, p.rhd) * p.hd) >> 1;
             const float2 cs = *reinterpret_cast<const float2*>(p.rope_cos + (int64_t)t * (p.hd / 2) + jd);
@@ -170,9 +171,11 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         if (sec < 2) {
             const float c0 = e.a.x, c1 = e.a.y, s0 = e.a.z, s1 = e.a.w;
             float o[4] = {fmaf(v[0], c0, -(v[1] * s0)), fmaf(v[0], s0, v[1] * c0), fmaf(v[2], c1, -(v[3] * s1)), fmaf(v[2], s1, v[3] * c1)};
+            if (p.abl == 7) return;
             if (sec == 0) store4p(p.q, p.q_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
             else store4p(p.k, p.k_plane, p.qkv_np, (int64_t)m * p.D + nn, o);
         } else {
+            if (p.abl == 6) return;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int c = nn + i;
@@ -1276,30 +1279,44 @@ __global__ void __launch_bounds__(NTHREADS) band_ffn_kernel(const BandDev p) {
         issue(q + NSLOT - 1);                     // -> slot (q-1) % NSLOT
         return ring + (q & (NSLOT - 1)) * 16384;
     };
+    // fragment reads run one k-step ahead of the MFMAs that use them (one wave per SIMD: an LDS round trip in front of every batch of
+    // six MFMAs was as long as the batch)
     auto phase_a = [&](int kc, const unsigned char* Bs) {
+        bf16x8 bf[2][2];
+        auto rd = [&](int ks, int slot) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<64>(wc * 64 + j * 32 + frow, ks * 2 + fk));
+        };
+        rd(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 bf[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<64>(wc * 64 + j * 32 + frow, ks * 2 + fk));
+            if (ks + 1 < 4) rd(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], ay[i][kc * 4 + ks], acc1[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][j], ay[i][kc * 4 + ks], acc1[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto phase_b = [&](const unsigned char* Bs, int khalf) {
+        bf16x8 af[2][3], bf[2][3];
+        auto rd = [&](int ks, int slot) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[slot][i] = *reinterpret_cast<const bf16x8*>(Hs + lds_off_t<64>(wr * 96 + i * 32 + frow, (khalf * 2 + ks) * 2 + fk));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<32>(wc * 96 + j * 32 + frow, ks * 2 + fk));
+        };
+        rd(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[3], bf[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Hs + lds_off_t<64>(wr * 96 + i * 32 + frow, (khalf * 2 + ks) * 2 + fk));
-#pragma unroll
-            for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<32>(wc * 96 + j * 32 + frow, ks * 2 + fk));
+            if (ks + 1 < 2) rd(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc2[i][j], 0, 0, 0);
+                for (int j = 0; j < 3; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][j], af[ks & 1][i], acc2[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     using std::integral_constant;
@@ -1386,7 +1403,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
     d.rT = 1.0f / (float)d.T; d.rhd = 1.0f / (float)d.hd; d.rD = 1.0f / (float)d.D;
     if (a.M >= (1 << 21) || (int64_t)a.N * (a.ngroups > 0 ? a.ngroups : 1) >= (1 << 21)) VB_FAIL(VB_E_INVALID, "gemm: index ranges exceed fdiv()");
-    d.trace = g_gemm_trace;
+    d.trace = g_gemm_trace; d.abl = vb_tune().gemm_ablate;
     const double gz_ = (a.group_off || a.ngroups <= 1) ? 1.0 : (double)a.ngroups;        // groups that share the row range multiply the work
     const double npl_ = a.nseg == 3 ? 2.0 : 1.0, MN_ = (double)a.M * a.N * gz_;
     double ob_;                                                                         // result (+ read-modify) bytes of the epilogue
