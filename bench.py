@@ -136,7 +136,8 @@ class Telemetry:
         if self.cards:
             self.thread.join(timeout=1.0)
 
-    def summary(self):
+    def summary(self, device=None):
+        """this rank's card only (matched by PCI address; failing that, the card drawing the most power during the timed region)"""
         if not self.samples:
             return {}
         res = {}
@@ -145,9 +146,26 @@ class Telemetry:
             pw = [s[ci][1] for s in self.samples if s[ci][1]]
             cap = [s[ci][2] for s in self.samples if s[ci][2]]
             res[d.split("/")[4]] = {"sclk_mhz_min": min(mhz) if mhz else None, "sclk_mhz_max": max(mhz) if mhz else None,
+                                    "sclk_mhz_avg": round(sum(mhz) / len(mhz)) if mhz else None,
                                     "power_w_avg": round(sum(pw) / len(pw), 1) if pw else None, "power_cap_w": cap[0] if cap else None,
-                                    "samples": len(self.samples)}
-        return res
+                                    "samples": len(self.samples), "sysfs": os.path.realpath(d)}
+        mine, how = None, None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            hit = [k for k, v in res.items() if addr in v["sysfs"].lower()]
+            if len(hit) == 1:
+                mine, how = hit[0], f"PCI address {addr}"
+        except Exception:
+            pass
+        if mine is None:
+            mine = max(res, key=lambda k: res[k]["power_w_avg"] or 0.0)
+            how = "highest average power among the box's cards during the timed region"
+        out = dict(res[mine])
+        out.pop("sysfs", None)
+        out.update(card=mine, matched_by=how, cards_on_box=len(res))
+        return out
 
 
 def parse():
@@ -378,8 +396,9 @@ def main():
     ctx = Context(device)
     S = max(1, args.streams)
     B = args.batch
-    assert B % S == 0, "--batch must be divisible by --streams"
-    Bs = B // S
+    assert S <= B, "--streams must not exceed --batch"
+    sizes = [B // S + (1 if i < B % S else 0) for i in range(S)]        # uneven splits allowed (8 clips on 3 streams: 3 + 3 + 2)
+    Bs = "+".join(str(n) for n in sizes) if B % S else str(B // S)
     idx, dts = vm.euler_tables(args.flow_steps + 1)
 
     def make_worker(nclips, clip_base, share=None):
@@ -394,7 +413,7 @@ def main():
     # host thread: kernels of different sub-batches overlap on the GPU and fill each other's tile-quantisation tails.
     workers = []
     for si in range(S):
-        workers.append(make_worker(Bs, rank * B + si * Bs, share=workers[0]["eng"] if workers else None))
+        workers.append(make_worker(sizes[si], rank * B + sum(sizes[:si]), share=workers[0]["eng"] if workers else None))
 
     def one_pass(w, k):
         if long:
@@ -546,7 +565,7 @@ def main():
                        if any(w["eng"].graphs() for w in workers) else "eager launches",
                        "streams_per_gpu": S, "parallelism": f"batch-shard x{world} ({S} concurrent sub-batches of {Bs} clips per GPU)"},
             "parity_check": parity,
-            "device": {"name": torch.cuda.get_device_name(device), "clocks_during_timed_region": tele.summary()},
+            "device": {"name": torch.cuda.get_device_name(device), "clocks_during_timed_region": tele.summary(device)},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "how": ("dominant class = largest GPU time per pass; achieved = algorithmic flops of its event-timed launches / their "
                                  "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 5th "
