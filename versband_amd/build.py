@@ -42,6 +42,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     dg = _digest()
     if not force and is_current():
         return LIB
+    # one builder at a time: N ranks of a bench / test launch may all find a stale stamp at once and must not link over each other
+    import fcntl
+    lock = open(os.path.join(OBJ, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and is_current():      # another process built it while we waited
+            return LIB
+        return _build_locked(dg, stamp, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(dg: str, stamp: str, verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
     def cc(src):
@@ -53,9 +67,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return out
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    tmp = LIB + f".tmp{os.getpid()}"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stderr)
+    os.replace(tmp, LIB)                     # atomic: a process that already mapped the old library keeps its inode
     with open(stamp, "w") as f:
         f.write(dg)
     if verbose:
