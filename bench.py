@@ -315,24 +315,27 @@ def cpu_worker(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def parity_check(z0, mel0):
+def parity_check(z0, mel0, fixture="bench_clip0.npz"):
     """clip 0 of the first timed pass (bf16 production precision, router noise drawn on the device) against the oracle's replay of
-    exactly that clip (tests/golden/bench_clip0.npz, written by oracle/gen_bench_digest.py from the CPU oracle + the host
-    restatement of the device noise stream): north_star's tolerances, latent rel-L2 <= 1e-3 and mel L1 < 1e-3."""
+    exactly that clip (tests/golden/bench_clip0*.npz, written by oracle/gen_bench_digest.py from the CPU oracle + the host
+    restatement of the device noise stream; one fixture per bench workload): north_star's tolerances, latent rel-L2 <= 1e-3 and
+    mel L1 < 1e-3."""
     import numpy as np
-    path = os.path.join(ROOT, "tests", "golden", "bench_clip0.npz")
+    path = os.path.join(ROOT, "tests", "golden", fixture)
     if not os.path.exists(path):
-        return {"ok": None, "why": "tests/golden/bench_clip0.npz missing"}
+        return {"ok": None, "why": f"tests/golden/{fixture} missing"}
     g = np.load(path)
     z_ref = torch.from_numpy(g["z"]).double()
     z = z0.detach().double().cpu()
+    if tuple(z.shape) != tuple(z_ref.shape):
+        return {"ok": None, "why": f"fixture holds a latent of shape {tuple(z_ref.shape)}, this run made {tuple(z.shape)}"}
     rel = float((z - z_ref).norm() / z_ref.norm())
     m = mel0.detach().double().cpu().reshape(-1)
     idx = torch.from_numpy(g["mel_idx"])
     l1 = float((m[idx] - torch.from_numpy(g["mel_val"])).abs().mean())
     l2 = abs(float(m.norm()) - float(g["mel_l2"][0])) / float(g["mel_l2"][0])
     return {"ok": bool(rel <= 1e-3 and l1 < 1e-3 and l2 <= 1e-3), "latent_rel_l2": rel, "mel_l1_sampled": l1, "mel_l2_rel": l2, "tol": 1e-3,
-            "against": "tests/golden/bench_clip0.npz (CPU oracle replay of clip 0, pass 0: same seed, same device-keyed router noise)"}
+            "against": f"tests/golden/{fixture} (CPU oracle replay of clip 0, pass 0: same seed, same device-keyed router noise)"}
 
 
 def main():
@@ -525,10 +528,17 @@ def main():
     L.check(lib.vb_prof_enable(0), "prof")
 
     parity = None
-    if rank == 0 and not args.no_parity_check and args.workload == "c2" and args.flow_steps == 50 and args.scale == 3.0 \
-            and args.precision == "bf16" and abs(args.seconds - 20.0) < 1e-9 and args.steps >= 1:
-        parity = parity_check(workers[0]["z0"], workers[0]["mel0"])
-        log(f"parity vs oracle digest: {parity}")
+    if rank == 0 and not args.no_parity_check and args.flow_steps == 50 and args.scale == 3.0 and args.precision == "bf16" and args.steps >= 1:
+        # one oracle fixture per workload shape: 20 s clips with 4 / 8 experts (clip 0 does not depend on the batch it rides in), and
+        # the 120 s long-form clip whose window rows / noise keys depend on the batch (4)
+        fixture = None
+        if not long and abs(args.seconds - 20.0) < 1e-9 and args.experts in (4, 8):
+            fixture = "bench_clip0.npz" if args.experts == 4 else "bench_clip0_e8.npz"
+        elif long and abs(args.seconds - 120.0) < 1e-9 and args.experts == 4 and args.batch == 4 and S == 1:
+            fixture = "bench_clip0_long.npz"
+        if fixture:
+            parity = parity_check(workers[0]["z0"], workers[0]["mel0"], fixture)
+            log(f"parity vs oracle digest: {parity}")
 
     if rank == 0:
         name, bound, peak = CLASSES[dominant]

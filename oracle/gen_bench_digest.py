@@ -6,7 +6,9 @@ bench.py's first timed pass exactly: 50 CFG Euler steps at T = 752, L = 80, scal
 committed as tests/golden/bench_clip0.npz (the oracle's latent in full + a digest of its mel) and bench.py / the GPU tests
 compare the HIP path's bf16 production output with it at north_star's tolerances.
 
-    python oracle/gen_bench_digest.py            # ~1-2 min of CPU
+    python oracle/gen_bench_digest.py            # ~1-2 min of CPU: configs[1] (E = 4) -> tests/golden/bench_clip0.npz
+    python oracle/gen_bench_digest.py --experts 8   # configs[2] (Band-MoE stress, E = 8) -> tests/golden/bench_clip0_e8.npz
+    python oracle/gen_bench_digest.py --long        # configs[4] (120 s long-form, batch 4: clip 0 = 4 windows of 1500) -> bench_clip0_long.npz, ~5 min
 """
 import os
 import sys
@@ -32,7 +34,7 @@ def digest(a, prefix, n_samples=256):
     return {prefix + k: v for k, v in d.items()}
 
 
-def device_noise(seed, clip, nfe, branch):
+def device_noise(seed, clip, nfe, branch, E=E, T=T):
     out = []
     for blk in range(DEPTH):
         out.append(tuple(torch.from_numpy(prng.device_router_exponentials(seed, clip, nfe, branch, blk, gate, T, w))
@@ -40,19 +42,51 @@ def device_noise(seed, clip, nfe, branch):
     return out
 
 
-def main():
+def main_long():
+    """bench.py --workload c5: 4 clips of 120 s (T = 4500) per GPU; versband_amd.longform.sample_long turns the windows into batch rows
+    (row = window * B + clip, noise key = clip_base * n_windows + row) and cross-fades them.  Clip 0 = rows 0, 4, 8, 12."""
+    from versband_amd.longform import crossfade_windows, plan_windows
+    B, TL, WIN, OV = 4, 4500, 1500, 128
     torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     dcfg, vcfg = synth.DiTConfig(), synth.VAEConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1)
+    inp = clip_batch(1, TL, L, clip0=0, seed=SEED)
+    plan = plan_windows(TL, WIN, OV)
+    midi, beats = inp["midi"].reshape(1, -1), inp["beats"].reshape(1, -1)
+    parts = []
+    for w, (s0, n) in enumerate(plan):
+        key = w * B + 0
+        cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], midi[:, 2 * s0:2 * (s0 + n)], beats[:, 2 * s0:2 * (s0 + n)], n)
+        cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], midi[:, 2 * s0:2 * (s0 + n)], beats[:, 2 * s0:2 * (s0 + n)], n)
+        parts.append(ref_cpu.sample_cfg(sd, inp["x_latent"][:, :, s0:s0 + n], cc, cu, SCALE, STEPS + 1,
+                                        lambda k, br, key=key, n=n: device_noise(SEED, key, k, br, 4, n)))
+        print("window", w, (s0, n), "done", flush=True)
+    z = crossfade_windows(parts, plan, TL)
+    mel = ref_cpu.vae_decode(sdv, z)
+    out = {"meta": np.array([SEED, TL, L, 4, STEPS, B, WIN, OV], dtype=np.int64), "scale": np.float32(SCALE), "z": z.numpy()}
+    out.update(digest(mel, "mel_"))
+    path = os.path.join(ROOT, "tests", "golden", "bench_clip0_long.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
+def main():
+    if "--long" in sys.argv:
+        return main_long()
+    E = int(sys.argv[sys.argv.index("--experts") + 1]) if "--experts" in sys.argv else 4
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    dcfg, vcfg = synth.DiTConfig(num_experts=E), synth.VAEConfig()
     sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
     sdv = synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1)
     inp = clip_batch(1, T, L, clip0=0, seed=SEED)
     cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
     cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], inp["midi"], inp["beats"], T)
-    z = ref_cpu.sample_cfg(sd, inp["x_latent"], cc, cu, SCALE, STEPS + 1, lambda k, br: device_noise(SEED, 0, k, br))
+    z = ref_cpu.sample_cfg(sd, inp["x_latent"], cc, cu, SCALE, STEPS + 1, lambda k, br: device_noise(SEED, 0, k, br, E))
     mel = ref_cpu.vae_decode(sdv, z)
     out = {"meta": np.array([SEED, T, L, E, STEPS], dtype=np.int64), "scale": np.float32(SCALE), "z": z.numpy()}
     out.update(digest(mel, "mel_"))
-    path = os.path.join(ROOT, "tests", "golden", "bench_clip0.npz")
+    path = os.path.join(ROOT, "tests", "golden", "bench_clip0.npz" if E == 4 else f"bench_clip0_e{E}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
 

@@ -105,3 +105,49 @@ def test_c2_bf16_production_vs_oracle(prod, B, steps):
     assert float((mel.cpu() - mel_ref).abs().mean()) < MEL_L1_TOL, describe("bf16 mel vs oracle", mel, mel_ref)
     # hard routing: flips can only come from near-ties of the two best gate values; they must stay a vanishing fraction
     assert flips.sum() <= 2e-3 * decisions * steps * 4, f"routing flip rate too high: {flips.sum(0).tolist()}"
+
+
+def _against_fixture(z, mel, name):
+    """the oracle's replay of bench.py's clip 0 (tests/golden/<name>, oracle/gen_bench_digest.py): latent in full, mel by digest"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    z_ref = torch.from_numpy(g["z"]).double()
+    z = z.detach().double().cpu()
+    assert tuple(z.shape) == tuple(z_ref.shape)
+    rel = float((z - z_ref).norm() / z_ref.norm())
+    m = mel.detach().double().cpu().reshape(-1)
+    l1 = float((m[torch.from_numpy(g["mel_idx"])] - torch.from_numpy(g["mel_val"])).abs().mean())
+    print(f"{name}: latent rel-L2 {rel:.3e}, mel L1 (sampled) {l1:.3e}")
+    assert rel <= LATENT_TOL and l1 < MEL_L1_TOL, f"{name}: latent rel-L2 {rel:.3e}, mel L1 {l1:.3e}"
+
+
+def test_c3_e8_bf16_production_clip_vs_oracle_fixture(ctx, prod):
+    """BASELINE configs[2] in the benchmarked precision: clip 0 of `bench.py --workload c3` (8 experts per group, router noise drawn
+    on the device) over all 50 CFG Euler steps + VAE decode against the oracle's replay; it rides in a batch of 3 here (a clip's
+    result does not depend on its batch)."""
+    from versband_amd.engine import DiTEngine
+    dcfg = synth.DiTConfig(num_experts=8)
+    eng = DiTEngine(ctx, dcfg, synth.make_state_dict(synth.dit_shapes(dcfg), SEED), precision="bf16")
+    T, Lc, B = 752, 80, 3
+    inp = clip_batch(B, T, Lc, clip0=0, seed=SEED)
+    idx, dts = vm.euler_tables(51)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    z = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=SEED, clip_base=0)
+    mel = prod["vae"].run(z[:1].contiguous())
+    torch.cuda.synchronize()
+    _against_fixture(z[:1], mel, "bench_clip0_e8.npz")
+
+
+def test_c5_longform_bf16_production_clip_vs_oracle_fixture(prod):
+    """BASELINE configs[4] in the benchmarked precision: clip 0 of `bench.py --workload c5` (4 x 120 s, T = 4500: four windows of 1500
+    as batch rows, linear cross-fade, VAE decode of the whole latent) against the oracle's replay of its four windows."""
+    from versband_amd import longform
+    T, Lc, B = 4500, 80, 4
+    inp = clip_batch(B, T, Lc, clip0=0, seed=SEED)
+    idx, dts = vm.euler_tables(51)
+    dev = "cuda:0"
+    z = longform.sample_long(prod["eng"], inp["x_latent"].to(dev), inp["t5_cond"].to(dev), inp["t5_uncond"].to(dev), inp["midi"].to(dev),
+                             inp["beats"].to(dev), idx, dts, 3.0, window=1500, overlap=128, seed=SEED, clip_base=0)
+    mel = prod["vae"].run(z[:1].contiguous())
+    torch.cuda.synchronize()
+    _against_fixture(z[:1], mel, "bench_clip0_long.npz")
