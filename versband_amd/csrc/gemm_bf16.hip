@@ -473,7 +473,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // ABL (tuning only): 1 = no tile DMA in the loop, 2 = no MFMA, 3 = no LDS fragment reads
 template <int EPI, int BKT, int NST, int ABL = 0>
-__global__ void __launch_bounds__(NTHREADS) gemm_bf16_glds_kernel(const GemmDev p) {
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BKT * NST == 96 ? 3 : 1, BKT * NST == 96 ? 3 : 8)))
+gemm_bf16_glds_kernel(const GemmDev p) {
     constexpr int CH = BKT / 8;              // 16-B chunks per tile row
     constexpr int RS = 64 / CH;              // tile rows covered by one wave-wide DMA (1 KB)
     constexpr int SPW = CH / 2;              // DMA pieces per wave per operand per tile
