@@ -545,7 +545,9 @@ def main():
         conc = (fl / (ms * 1e-3) / 1e12) if (ms > 0 and nt > 0) else 0.0      # flops and time of the timed launches
         iso = next((r for r in table if r["class"] == name), None)
         achieved = iso["tflops"] if iso else conc
-        traffic, traffic_file = pmc_traffic(dominant)
+        # the committed PMC passes were taken on the default command (c2, 8 clips): for any other workload the per-launch figure does not apply
+        pmc_applies = args.workload == "c2" and B == 8 and args.experts == 4 and abs(clip_seconds - 20.0) < 1e-9
+        traffic, traffic_file = pmc_traffic(dominant) if pmc_applies else (None, None)
         total_mel_s = world * B * clip_seconds * args.steps
         wl = {"c2": f"{B} x {clip_seconds:.0f} s clips per GPU (T_lat={T_lat}, T_mel={T_mel}, 24 kHz)",
               "c3": f"Band-MoE stress: {B} x {clip_seconds:.0f} s clips per GPU, num_experts={args.experts} ({2 * B * T_lat} token rows per evaluation)",
@@ -583,7 +585,9 @@ def main():
                          "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
                          "traffic": traffic,
                          "traffic_source": (f"file: {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per "
-                                            "the gfx950 note; PMC cannot be read in-process)") if traffic else None,
+                                            "the gfx950 note; PMC cannot be read in-process)") if traffic else
+                                           ("none for this workload: the committed PMC passes (profiles/r*_pmc_summary.json) are of the default c2 command"
+                                            if not pmc_applies else None),
                          "algorithmic_bytes_per_launch": (iso["algorithmic_mb_per_launch"] * 1e6) if iso else None,
                          "timed_region": ({"achieved": conc, "frac": conc / peak, "avg_launch_us": (1e3 * ms / nt) if nt else None,
                                            "launches_per_step": n / max(args.steps, 1), "timed_launches": nt,
