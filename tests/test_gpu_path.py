@@ -375,6 +375,39 @@ def test_fused_band_experts_match_two_gemm_path(engines, monkeypatch):
     assert torch.equal(v1, v2), describe("fused vs two-GEMM band experts", v1, v2)
 
 
+@pytest.mark.parametrize("E,B,T", [(4, 4, 752), (4, 6, 500), (8, 4, 752)])
+def test_fused_score_router_matches_two_launches(ctx, sds, engines, monkeypatch, E, B, T):
+    """The opt-in fused caption-gate kernel (VB_SCORE_FUSED=1, score_router.hip: a workgroup owns 64 tokens x all 640 score columns,
+    the scores stay in LDS, the router's own device code runs on them; measured slower than the two launches, kept as an experiment).
+    Same k-order, same bias add, same router code: routes, gate weights and the DiT output must be bit-identical to the grouped
+    score GEMM + router kernel, for full and ragged last tiles (T = 500 = 7 x 64 + 52), with injected and device noise."""
+    from versband_amd.engine import DiTEngine
+    eng = engines[(4, "bf16")] if E == 4 else DiTEngine(ctx, synth.DiTConfig(num_experts=8), sds[8], precision="bf16")
+    Lc = 80
+    inp = clip_batch(B, T, Lc)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2 * B,), 413, dtype=torch.int64)
+    noise = gumbel_arrays([exp_noise(B, T, E, 0, 4), exp_noise(B, T, E, 1, 4)]) if E == 4 and T == 752 else None
+    runs = []
+    for fused in (True, False):
+        if fused:
+            monkeypatch.setenv("VB_SCORE_FUSED", "1")
+        else:
+            monkeypatch.delenv("VB_SCORE_FUSED")
+        L.load().vb_tune_reload()
+        out = []
+        for kw in ([dict(seed=21)] + ([dict(noise=noise)] if noise is not None else [])):
+            v, r = eng.forward(inp["x_latent"], t_idx, cond, return_routes=True, **kw)
+            torch.cuda.synchronize()
+            out.append((v.clone(), r.clone()))
+        runs.append(out)
+    L.load().vb_tune_reload()
+    for (v1, r1), (v2, r2) in zip(*runs):
+        assert torch.isfinite(v1).all()
+        assert torch.equal(r1, r2), f"routes differ at {(r1 != r2).sum().item()} of {r1.numel()} decisions"
+        assert torch.equal(v1, v2), describe("fused score + router vs two launches", v1, v2)
+
+
 def test_fullsize_reference_digests(ctx, engines):
     """BASELINE geometry (one 20 s clip: T = 752, L = 80, T_mel = 1504) against digests of the REFERENCE's own outputs
     (tests/golden/fullsize_digests.npz): DiT forward in split precision on injected noise, VAE decode, VAE encode, HiFi-GAN."""

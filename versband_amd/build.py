@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libversband_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "respair_x3.hip", "t5.hip", "melnet.hip", "elementwise.hip", "rowlin.hip", "engine.hip"]
+SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "respair_x3.hip", "t5.hip", "melnet.hip", "elementwise.hip", "score_router.hip", "rowlin.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 

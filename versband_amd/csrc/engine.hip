@@ -32,6 +32,7 @@ static void tune_load() {
     t.conv_direct_epi = getenv("VB_CONV_DIRECT_EPI") != nullptr;
     t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
     t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr; t.moe_unfused = getenv("VB_MOE_UNFUSED") != nullptr;
+    t.score_fused = getenv("VB_SCORE_FUSED") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
     g_tune = t;
     g_tune_loaded = true;
@@ -420,6 +421,27 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         // ---- Band-MoE (vocal2music_moe.py:117-185)
         VB_TRY(launch_rmsnorm_mod(s.h, bw.ffn_norm_w, mod + 3 * D, mod + 4 * D, MODW, N, D, T, c.norm_eps, u, st));
         const bool fold = cd.fold && bw.wqt_s && bw.bq_s;
+        // gates: injected Gumbel arrays (parity path) or counter-based draws generated inside the router kernel
+        const float *g1 = nullptr, *g2 = nullptr, *g3 = nullptr;
+        if (noise && noise->g1) {
+            const size_t so = (size_t)noise_step * c.depth + i;
+            g1 = noise->g1 + so * N * 2; g2 = noise->g2 + so * N * E; g3 = noise->g3 + so * N * E;
+        }
+        // scores + router in one launch (score_router.hip: the [N][NS] score matrix stays in LDS; bit-identical to the two launches
+        // below).  MEASURED SLOWER - 91 us against 32 + 22 at 8 clips: its mainloop runs 36 us with one 4-wave workgroup per CU and the
+        // router's per-token wave-wide shuffles take 63 us without many waves per SIMD to hide them - so it is an opt-in experiment
+        // (VB_SCORE_FUSED=1), kept with its test as the record.
+        const bool fused_router = fold && np == 1 && vb_tune().score_fused && score_router_supported(cd.NS, D, E, c.heads) &&
+                                  (int64_t)Beff * cdiv(T, 64) >= 96;
+        if (fused_router) {
+            ScoreRouterArgs sr;
+            sr.A = u.p; sr.lda = D; sr.Bm = cd.mf[i]; sr.ldb = D; sr.bias = cd.cb[i]; sr.vw = cd.vw[i]; sr.bg = bw.bcg; sr.la = cd.la[i];
+            sr.la_rows = B * T; sr.hl = hl + i * 2; sr.hl_ld = hl_ld; sr.g1 = g1; sr.g2 = g2; sr.g3 = g3; sr.Beff = Beff; sr.B = B; sr.T = T;
+            sr.K = D; sr.NS = cd.NS; sr.Hh = c.heads; sr.E = E; sr.ic = s.ic; sr.ia = s.ia; sr.mc = s.mc; sr.ma = s.ma;
+            sr.seed = noise ? noise->seed : 0; sr.clip_base = noise ? noise->clip_base : 0; sr.nfe_base = noise ? noise->nfe : 0;
+            sr.step = step_ptr; sr.block = i;
+            VB_TRY(launch_score_router(sr, st));
+        } else {
         if (fold) {
             // caption gate, folded: scores of every token against its clip's caption keys for all heads in ONE grouped GEMM
             // (q-projection, q-bias and softmax scale live in the per-clip operand), then softmax + value/gate contraction +
@@ -442,15 +464,10 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         }
         // (MoE.cross_attention.out_proj is folded into the caption gate at pack time: lc = cqa . (Wcg Wo)^T + (Wcg bo + bcg),
         //  so the [N,768]x[768,768] out_proj GEMM never runs - its only consumer is the 768->E gate, vocal2music_moe.py:119-141)
-        // gates: injected Gumbel arrays (parity path) or counter-based draws generated inside the router kernel
-        const float *g1 = nullptr, *g2 = nullptr, *g3 = nullptr;
-        if (noise && noise->g1) {
-            const size_t so = (size_t)noise_step * c.depth + i;
-            g1 = noise->g1 + so * N * 2; g2 = noise->g2 + so * N * E; g3 = noise->g3 + so * N * E;
-        }
         VB_TRY(launch_router(cqa, fold ? cd.vw[i] : bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
                              s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st,
                              fold ? s.y32 : nullptr, cd.NS, c.heads));
+        }
         VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -157,6 +157,21 @@ int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, 
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
                   hipStream_t st, const float* sc = nullptr, int NS = 0, int Hh = 1);
+// fused caption-gate scores + router (score_router.hip): bf16 token features x per-clip folded keys -> routing decisions, the
+// [N][NS] score matrix stays in LDS.  Bit-identical to launch_gemm(EPI_F32 scores) + launch_router(sc = scores).
+struct ScoreRouterArgs {
+    const bf16_t* A = nullptr; int lda = 0;          // token features [Beff*T][lda] bf16
+    const bf16_t* Bm = nullptr; int ldb = 0;         // folded keys [Beff][NS][ldb] bf16
+    const float* bias = nullptr;                     // [Beff][NS]
+    const float* vw = nullptr;                       // [Beff][NS][E]
+    const float* bg = nullptr; const float* la = nullptr; int la_rows = 0; const float* hl = nullptr; int hl_ld = 0;
+    const float* g1 = nullptr; const float* g2 = nullptr; const float* g3 = nullptr;
+    int Beff = 0, B = 0, T = 0, K = 0, NS = 0, Hh = 1, E = 0;
+    int* ic = nullptr; int* ia = nullptr; float* mc = nullptr; float* ma = nullptr;
+    uint64_t seed = 0; int64_t clip_base = 0; int nfe_base = 0; const int* step = nullptr; int block = 0;
+};
+bool score_router_supported(int NS, int K, int E, int Hh);
+int launch_score_router(const ScoreRouterArgs& a, hipStream_t st);
 int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st);
 int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this many ints
