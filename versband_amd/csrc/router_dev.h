@@ -71,6 +71,71 @@ struct RouterDev {
     const float* g1; const float* g2; const float* g3; int N, T, D, E; int* ic; int* ia; float* mc; float* ma; float* lc_out; int B;
     uint64_t seed; int64_t clip_base; int nfe_base; const int* step; int block; const float* sc; int NS, Hh;
 };
+// Phase B of the router for the RT_TPW tokens n0 .. of one wave: noise draws, arg-max, high-level gate.  A token needs 2E+2 "slots"
+// (E caption-gate, E acoustic-gate, 2 high-level-gate values): PP tokens are laid side by side in the wave (SPT = 64/PP lanes each), so
+// the counter-based noise generator, the index arithmetic and the arg-max loops run once per PP tokens.  logit_of(t0, tokq, sl) returns
+// the caption-gate logit (before the bias) of token n0 + t0 + tokq and expert sl; it is called by ALL lanes (it may shuffle).
+template <int PP, int RT_TPW, typename LogitFn>
+__device__ __forceinline__ void router_phase_b(const RouterDev& a, const int n0, const int N, LogitFn&& logit_of) {
+    const float* __restrict__ bg = a.bg; const float* __restrict__ la = a.la;
+    const int la_rows = a.la_rows; const float* __restrict__ hl = a.hl; const int hl_ld = a.hl_ld;
+    const float* __restrict__ g1 = a.g1; const float* __restrict__ g2 = a.g2; const float* __restrict__ g3 = a.g3;
+    const int T = a.T, E = a.E, B = a.B, block = a.block;
+    int* ic = a.ic; int* ia = a.ia; float* mc = a.mc; float* ma = a.ma; float* lc_out = a.lc_out;
+    uint64_t seed = a.seed; int64_t clip_base = a.clip_base; int nfe_base = a.nfe_base; const int* step = a.step;
+    const int lane = threadIdx.x & 63;
+    constexpr int SPT = 64 / PP;
+    const bool gen = g1 == nullptr;
+    if (step) {
+        // sampler path: the noise key lives in the device-side parameter block behind the step counter (launch_sampler_params), so
+        // a captured graph of the step loop can be replayed for another seed / clip base without re-capturing
+        const long long* prm = reinterpret_cast<const long long*>(step + 4);
+        seed = (uint64_t)prm[0]; clip_base = prm[1]; nfe_base = (int)prm[2];
+    }
+    const int nfe = nfe_base + (step ? *step : 0);
+    const int tokq = lane / SPT, sl = lane % SPT, lbase = lane - sl;
+#pragma unroll
+    for (int t0 = 0; t0 < RT_TPW; t0 += PP) {
+        const int n = n0 + t0 + tokq;
+        const bool valid = n < N;
+        const int nn = valid ? n : N - 1;
+        const int bb = nn / T, tt = nn - bb * T;
+        const int branch = bb / B;
+        const int64_t clip = clip_base + (bb - branch * B);
+        const int gate = sl < E ? 1 : (sl < 2 * E ? 2 : 0);
+        const int slot = sl < E ? sl : (sl < 2 * E ? sl - E : sl - 2 * E);
+        // this lane's side input: caption gate bias / acoustic gate logit / high-level gate logit; and its noise value
+        float sv = 0.f, nz = 0.f;
+        if (sl < 2 * E + 2) {
+            if (gate == 1) sv = bg[slot];
+            else if (gate == 2) sv = la[(int64_t)(nn % la_rows) * E + slot];
+            else sv = hl[bb * hl_ld + slot];
+            if (gen) nz = gumbel_draw(seed, clip, nfe, branch, block, gate, tt, gate == 0 ? 2 : E, slot);
+            else nz = gate == 1 ? g2[(int64_t)nn * E + slot] : (gate == 2 ? g3[(int64_t)nn * E + slot] : g1[(int64_t)nn * 2 + slot]);
+        }
+        const float mylogit = logit_of(t0, tokq, sl);     // caption-gate logit of this lane's (token, expert) before the bias; lanes with sl >= E: unused
+        const float zl = (sl < E ? mylogit : 0.f) + sv;      // gate logit of this lane's (token, gate, slot)
+        if (lc_out && valid && sl < E) lc_out[(int64_t)n * E + sl] = zl;
+        const float z = zl + nz;
+        float best = -INFINITY, bz = -INFINITY; int bi = 0, ba = 0;
+        for (int e = 0; e < E; ++e) {
+            const float zc = __shfl(z, lbase + e, 64), za = __shfl(z, lbase + E + e, 64);
+            if (zc > best) { best = zc; bi = e; }
+            if (za > bz) { bz = za; ba = e; }
+        }
+        const float z0 = __shfl(z, lbase + 2 * E, 64), z1 = __shfl(z, lbase + 2 * E + 1, 64);
+        if (valid && sl == 0) {
+            ic[n] = bi;
+            ia[n] = ba;
+            const float m = fmaxf(z0, z1);
+            const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+            const float inv = 1.f / (e0 + e1);
+            mc[n] = e0 * inv;
+            ma[n] = e1 * inv;
+        }
+    }
+}
+
 // One wave, tokens n0 .. n0 + RT_TPW - 1 (n0 < N).  `N` bounds the tokens this call may touch (the launch's token count, or the end of
 // the caller's clip tile); rows of the score matrix are read from sc_row0 + (n - n0) * sc_ld (global memory or LDS: a flat pointer);
 // rt_ws = gate weights staged in LDS by the caller (SC = false only).
@@ -195,41 +260,10 @@ __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, 
             for (int tok = 0; tok < RT_TPW; ++tok) parts[tok][e] = acc[tok];
         }
     }
-    // phase B: noise draws, logit reduction, arg-max, high-level gate.  A token needs 2E+2 "slots" (E caption-gate,
-    // E acoustic-gate, 2 high-level-gate values): PP tokens are laid side by side in the wave (SPT = 64/PP lanes each), so
-    // the counter-based noise generator, the index arithmetic and the arg-max loops run once per PP tokens.
-    constexpr int SPT = 64 / PP;
-    const bool gen = g1 == nullptr;
-    if (step) {
-        // sampler path: the noise key lives in the device-side parameter block behind the step counter (launch_sampler_params), so
-        // a captured graph of the step loop can be replayed for another seed / clip base without re-capturing
-        const long long* prm = reinterpret_cast<const long long*>(step + 4);
-        seed = (uint64_t)prm[0]; clip_base = prm[1]; nfe_base = (int)prm[2];
-    }
-    const int nfe = nfe_base + (step ? *step : 0);
-    const int tokq = lane / SPT, sl = lane % SPT, lbase = lane - sl;
-#pragma unroll
-    for (int t0 = 0; t0 < RT_TPW; t0 += PP) {
-        const int n = n0 + t0 + tokq;
-        const bool valid = n < N;
-        const int nn = valid ? n : N - 1;
-        const int bb = nn / T, tt = nn - bb * T;
-        const int branch = bb / B;
-        const int64_t clip = clip_base + (bb - branch * B);
-        const int gate = sl < E ? 1 : (sl < 2 * E ? 2 : 0);
-        const int slot = sl < E ? sl : (sl < 2 * E ? sl - E : sl - 2 * E);
-        // this lane's side input: caption gate bias / acoustic gate logit / high-level gate logit; and its noise value
-        float sv = 0.f, nz = 0.f;
-        if (sl < 2 * E + 2) {
-            if (gate == 1) sv = bg[slot];
-            else if (gate == 2) sv = la[(int64_t)(nn % la_rows) * E + slot];
-            else sv = hl[bb * hl_ld + slot];
-            if (gen) nz = gumbel_draw(seed, clip, nfe, branch, block, gate, tt, gate == 0 ? 2 : E, slot);
-            else nz = gate == 1 ? g2[(int64_t)nn * E + slot] : (gate == 2 ? g3[(int64_t)nn * E + slot] : g1[(int64_t)nn * 2 + slot]);
-        }
-        // E partial dot products per lane, reduced together: after exchanging with lane^32 a lane keeps half of the
-        // experts, after lane^16 a quarter, ... then the remaining value is summed over the rest of the wave
-        // (7 shuffles for E = 4 instead of 24); lane e then holds logit e, from where the token's own lanes fetch it.
+    // phase B (router_phase_b): the E partial dot products per lane are reduced together: after exchanging with lane^32 a lane keeps
+    // half of the experts, after lane^16 a quarter, ... then the remaining value is summed over the rest of the wave (7 shuffles for
+    // E = 4 instead of 24); lane e then holds logit e, from where the token's own lanes fetch it.
+    auto logit_of = [&](int t0, int tokq, int sl) __attribute__((always_inline)) {
         float mylogit = 0.f;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
@@ -249,24 +283,7 @@ __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, 
             const float v = __shfl(logit_e, sl < E ? sl : 0, 64);
             if (tokq == j) mylogit = v;
         }
-        const float zl = (sl < E ? mylogit : 0.f) + sv;      // gate logit of this lane's (token, gate, slot)
-        if (lc_out && valid && sl < E) lc_out[(int64_t)n * E + sl] = zl;
-        const float z = zl + nz;
-        float best = -INFINITY, bz = -INFINITY; int bi = 0, ba = 0;
-        for (int e = 0; e < E; ++e) {
-            const float zc = __shfl(z, lbase + e, 64), za = __shfl(z, lbase + E + e, 64);
-            if (zc > best) { best = zc; bi = e; }
-            if (za > bz) { bz = za; ba = e; }
-        }
-        const float z0 = __shfl(z, lbase + 2 * E, 64), z1 = __shfl(z, lbase + 2 * E + 1, 64);
-        if (valid && sl == 0) {
-            ic[n] = bi;
-            ia[n] = ba;
-            const float m = fmaxf(z0, z1);
-            const float e0 = expf(z0 - m), e1 = expf(z1 - m);
-            const float inv = 1.f / (e0 + e1);
-            mc[n] = e0 * inv;
-            ma[n] = e1 * inv;
-        }
-    }
+        return mylogit;
+    };
+    router_phase_b<PP, RT_TPW>(a, n0, N, logit_of);
 }
