@@ -227,7 +227,7 @@ def test_router_top1_bit_exact(lib, E):
     assert torch.equal(idx.cpu().long(), ref), f"{int((idx.cpu().long() != ref).sum())} of {N} routing indices differ"
 
 
-@pytest.mark.parametrize("N,E", [(1, 4), (1000, 4), (12032, 4), (3000, 8)])
+@pytest.mark.parametrize("N,E", [(1, 4), (1000, 4), (1504, 4), (4096, 4), (4097, 4), (12032, 4), (3000, 8), (6016, 8)])
 def test_route_bucket(lib, N, E):
     ic = torch.from_numpy(prng.randint(3, N, 0, E)).int()
     ia = torch.from_numpy(prng.randint(4, N, 0, E)).int()
