@@ -354,11 +354,14 @@ def test_eight_wave_gemm_matches_four_wave_kernels(engines, monkeypatch):
         assert torch.equal(outs[0][0], outs[1][0]), describe(f"8-wave vs 4-wave GEMM ({prec})", outs[1][0], outs[0][0])
 
 
-def test_fused_band_experts_match_two_gemm_path(engines, monkeypatch):
-    """bf16 production mode runs the band experts as ONE launch (w1/w3 -> SwiGLU -> w2, hidden kept in LDS); it walks K in
-    the same order as the two grouped GEMMs and shares their epilogue code, so the results must be bit-identical."""
-    eng = engines[(4, "bf16")]
-    B, T, Lc = 2, 752, 80
+@pytest.mark.parametrize("E,B,T", [(4, 2, 752), (8, 3, 752), (8, 4, 700)])
+def test_fused_band_experts_match_two_gemm_path(ctx, sds, engines, monkeypatch, E, B, T):
+    """bf16 production mode runs the band experts as ONE launch (w1/w3 -> SwiGLU -> w2, hidden kept in LDS; 192-channel bands at
+    4 experts, 96-channel bands at 8); it walks K in the same order as the two grouped GEMMs and uses their epilogue arithmetic, so
+    the results must be bit-identical (T = 700: the last 256-token tile of the batch is ragged)."""
+    from versband_amd.engine import DiTEngine
+    eng = engines[(4, "bf16")] if E == 4 else DiTEngine(ctx, synth.DiTConfig(num_experts=8), sds[8], precision="bf16")
+    Lc = 80
     inp = clip_batch(B, T, Lc)
     cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
     t_idx = torch.full((2 * B,), 777, dtype=torch.int64)

@@ -493,7 +493,8 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         // (a fused workgroup owns 192 tokens x one band for ~50 us whatever the batch: below ~128 workgroups - half a round of the
         //  CUs, i.e. fewer than 4 clips x 2 branches - the two grouped GEMMs, bit-identical, are faster: 55.4 -> 50.4 ms per pass at
         //  one clip, 69.9 -> 65.3 at two, break-even at four, profiles/r02_band_small_batch.txt)
-        if (np == 1 && band == 192 && H % 64 == 0 && E <= 8 && 8 % E == 0 && !band_unfused && (int64_t)cdiv(N, 192) * E >= 128) {
+        if (np == 1 && (band == 192 || band == 96) && H % 64 == 0 && E <= 8 && 8 % E == 0 && !band_unfused &&
+            (int64_t)cdiv(N, band == 192 ? 192 : 256) * E >= 128) {
             // both products in one launch, hidden kept in LDS (bf16 production mode; independent of the batch size)
             BandFfnArgs bf;
             bf.y = y.p; bf.ldy = D; bf.w13 = (const bf16_t*)bw.w13f; bf.w2 = (const bf16_t*)bw.w2f; bf.M = N; bf.H = H; bf.E = E;

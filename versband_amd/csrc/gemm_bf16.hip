@@ -1363,8 +1363,174 @@ __global__ void __launch_bounds__(NTHREADS) band_ffn_kernel(const BandDev p) {
     }
 }
 
+// ---- band-expert FFN, fused, 96-channel bands (8 experts per group, BASELINE configs[2]) ------------------------------------
+// Same idea as band_ffn_kernel for band = 96: at E = 8 the hidden tensor of the band experts is [N][8 x 512] bf16 - 394 MB written by
+// the w1/w3 GEMM and read back by the w2 GEMM per block evaluation at 32 clips (306 + 166 us, profiles/r02_final_c3_kernel_stats.csv).
+// One workgroup owns 256 tokens x one band; 4 waves, wave w owns rows [64 w, 64 w + 64) in BOTH products (2 row tiles; 4 column tiles
+// of the 128-column w1/w3 chunk, 3 column tiles of the 96 outputs), so a wave reads back only the hidden values it wrote itself:
+//   * y_e [64 x 96] per wave lives in registers (2 x 6 fragments);
+//   * per 64-wide hidden chunk 4 loads through a ring of eight 12-KB slots, seven ahead: three K-slabs of w13 [128 rows x 32] (8 KB,
+//     2 DMA pieces per wave) and the w2 slab [96 rows x 64] (12 KB, 3 pieces per wave); counted vmcnt (pattern 2 2 2 3);
+//   * acc1 [64 x 128] -> SwiGLU lane-locally -> bf16 hidden chunk [64 x 64] in LDS -> acc2 [64 x 96] += hidden . w2 slab;
+//   * gated residual epilogue straight from the MFMA layout (wave_epilogue<EPI_RESID_GATE>): a lane owns one row and 4 consecutive
+//     columns, 16-byte loads / stores.
+// k runs ascending in both products, as in the grouped GEMMs: bit-identical to the unfused path.
+#define B96_BM 256
+#define B96_BAND 96
+#define B96_SLOT 12288
+__global__ void __launch_bounds__(NTHREADS) band_ffn96_kernel(const BandDev p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bl96[];
+    constexpr int HCH = B96_BM * 128;             // bytes of the [256 x 64] bf16 hidden chunk
+    constexpr int NSLOT = 8;
+    unsigned char* Hs = bl96;
+    unsigned char* ring = bl96 + HCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fk = lane >> 5;
+    const int L = blockIdx.x;
+    const int e = (L & 7) % p.E;
+    const int rt = (L >> 3) * (8 / p.E) + (L & 7) / p.E;
+    const int row0 = rt * B96_BM;
+    if (row0 >= p.M) return;
+    const int rows_end = p.M;
+
+    bf16x8 ay[2][6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int row = row0 + wave * 64 + i * 32 + frow;
+        if (row >= rows_end) row = row0;
+        const bf16_t* src = p.Y + (int64_t)row * p.ldy + e * B96_BAND + fk * 8;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) ay[i][kk] = *reinterpret_cast<const bf16x8*>(src + kk * 16);
+    }
+    const bf16_t* w13 = p.W13 + (int64_t)e * 2 * p.H * B96_BAND;
+    const bf16_t* w2 = p.W2 + (int64_t)e * B96_BAND * p.H;
+    int a_off[2], b_off[3];          // element offsets of this lane's DMA pieces inside a w13 K-slab / the w2 slab
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 16 * (wave * 2 + i) + (lane >> 2);                  // 16 rows x 64 B per piece
+        a_off[i] = r * B96_BAND + (((lane & 3) ^ ((r >> 2) & 3)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = 8 * (wave * 3 + i) + (lane >> 3);                   // 8 rows x 128 B per piece
+        b_off[i] = r * p.H + (((lane & 7) ^ ((r >> 1) & 7)) << 3);
+    }
+    const int nchunk = p.H / 64;
+    const int nload = nchunk * 4;
+    auto issue = [&](int q) {
+        unsigned char* dst = ring + (q & (NSLOT - 1)) * B96_SLOT;
+        while (q >= nload) q -= 4;                // past the end: same-typed dummy reload into a dead slot (keeps the counted vmcnt pattern)
+        const int hc = q >> 2, t = q & 3;
+        if (t < 3) {
+            const bf16_t* src = w13 + (int64_t)hc * 128 * B96_BAND + t * 32;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + a_off[i]), (lds_ptr_t)(dst + (wave * 2 + i) * 1024), 16, 0, 0);
+        } else {
+            const bf16_t* src = w2 + hc * 64;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + b_off[i]), (lds_ptr_t)(dst + (wave * 3 + i) * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < NSLOT - 1; ++q) issue(q);
+
+    f32x16 acc1[2][4], acc2[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
+    // step q multiplies load q; loads q+1 .. q+6 (already issued) may stay in flight: AHEAD = their DMA pieces per wave
+    auto step_begin = [&](int q, auto ahead) -> const unsigned char* {
+        wait_vmcnt<decltype(ahead)::value>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // own LDS traffic done before the barrier
+        __builtin_amdgcn_s_barrier();             // load q landed everywhere; everyone is done with load q-1's slot
+        issue(q + NSLOT - 1);                     // -> slot (q-1) % NSLOT
+        return ring + (q & (NSLOT - 1)) * B96_SLOT;
+    };
+    auto phase_a = [&](int t, const unsigned char* Bs) {
+        bf16x8 bf[2][4];
+        auto rd = [&](int ks, int slot) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<32>(j * 32 + frow, ks * 2 + fk));
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks + 1 < 2) rd(ks + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], ay[i][t * 2 + ks], acc1[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto phase_b = [&](const unsigned char* Bs) {
+        bf16x8 af[2][2], bf[2][3];
+        auto rd = [&](int ks, int slot) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const bf16x8*>(Hs + lds_off_t<64>(wave * 64 + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<64>(j * 32 + frow, ks * 2 + fk));
+        };
+        rd(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) rd(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][j], af[ks & 1][i], acc2[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int hc = 0; hc < nchunk; ++hc) {
+        const int q0 = hc * 4;
+        // pieces per wave of the six loads behind the consumed one (pattern A2 A2 A2 B3, cyclic)
+        phase_a(0, step_begin(q0 + 0, integral_constant<int, 13>()));
+        phase_a(1, step_begin(q0 + 1, integral_constant<int, 14>()));
+        phase_a(2, step_begin(q0 + 2, integral_constant<int, 14>()));
+        {
+            // SwiGLU on the interleaved (w1, w3) column pairs -> this chunk's hidden values (rows of this wave only), bf16
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = wave * 64 + i * 32 + frow;
+                        const int h0 = j * 16 + q * 4 + fk * 2;
+                        bf16x2 hv;
+                        hv[0] = f2bf(silu_f(acc1[i][j][q * 4 + 0]) * acc1[i][j][q * 4 + 1]);
+                        hv[1] = f2bf(silu_f(acc1[i][j][q * 4 + 2]) * acc1[i][j][q * 4 + 3]);
+                        *reinterpret_cast<bf16x2*>(Hs + lds_off_t<64>(row, h0 >> 3) + (h0 & 7) * 2) = hv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc1[i][j][q * 4 + r] = 0.f;
+                    }
+        }
+        phase_b(step_begin(q0 + 3, integral_constant<int, 13>()));
+    }
+    wait_vmcnt<0>();                              // the dummy tail loads
+    // gated residual: h[:, band e] += gate * z   (same arithmetic as the unfused w2 GEMM's epilogue)
+    wave_epilogue<EPI_RESID_GATE, 2, 3>(p.ep, e, acc2, row0 + wave * 64, rows_end, 0, frow, fk);
+}
+
 int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
-    if (a.band != BF_BAND || a.H % 64 || (8 % a.E) || a.E > 8) VB_FAIL(VB_E_INVALID, "band_ffn: band=%d H=%d E=%d unsupported", a.band, a.H, a.E);
+    if ((a.band != BF_BAND && a.band != B96_BAND) || a.H % 64 || (8 % a.E) || a.E > 8) VB_FAIL(VB_E_INVALID, "band_ffn: band=%d H=%d E=%d unsupported", a.band, a.H, a.E);
     BandDev d;
     memset(&d, 0, sizeof(d));
     d.Y = a.y; d.ldy = a.ldy; d.W13 = a.w13; d.W2 = a.w2; d.M = a.M; d.H = a.H; d.E = a.E;
@@ -1372,6 +1538,19 @@ int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
     d.ep.rT = 1.0f / (float)d.ep.T; d.ep.rhd = 1.f; d.ep.rD = 1.f; d.ep.hd = 1; d.ep.D = 1;
     d.ep.c_noff_group = a.band; d.ep.N = a.band; d.ep.M = a.M; d.ep.trace = g_gemm_trace;
     if (a.M >= (1 << 21)) VB_FAIL(VB_E_INVALID, "band_ffn: M exceeds fdiv()");
+    if (a.band == B96_BAND) {
+        const int tiles96 = cdiv(a.M, B96_BM);
+        const int nblk96 = cdiv(tiles96, 8 / a.E) * 8;
+        constexpr size_t lds96 = (size_t)B96_BM * 128 + 8 * B96_SLOT;      // hidden chunk (32 KB) + 8 ring slots of 12 KB = 128 KB
+        static OnceFlags attr96;
+        if (vb_first_use_on_device(attr96))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_ffn96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds96);
+        ProfScope prof96(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H),
+                         (double)a.M * a.E * a.band * (2.0 + 8.0) + (double)a.E * 3.0 * a.H * a.band * 2.0, st);
+        hipLaunchKernelGGL(band_ffn96_kernel, dim3(nblk96), dim3(NTHREADS), lds96, st, d);
+        VB_CHECK_LAUNCH();
+        return VB_OK;
+    }
     const int row_tiles = cdiv(a.M, BF_BM);
     const int per8 = 8 / a.E;                         // row tiles per group of 8 consecutive blocks
     const int nblk = cdiv(row_tiles, per8) * 8;
