@@ -34,6 +34,7 @@ L_CTX = 80
 SEED = 1234
 HBM_PEAK_TBS = 8.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s float4-copy rate measured)
 MFMA_BF16_TF = 2500.0       # dense bf16 MFMA peak
+MFMA_F32_TF = 157.3         # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32), the roof of --vocoder-precision fp32
 # kernel classes of the library's HIP-event profiler (csrc/kernels.h): name, binding roof, peak TFLOP/s
 CLASSES = {
     0: ("bf16 MFMA GEMM (DiT projections, routed + band experts)", "mfma", MFMA_BF16_TF),
@@ -86,6 +87,46 @@ def pmc_traffic(cls):
         return ((tot / n) if n else None), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
+
+
+def pmc_traffic_live(cls, timeout):
+    """HBM bytes per launch of a kernel class MEASURED IN THIS RUN: two child runs of this same command (one stream, one pass, no
+    baseline legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes: the two counters do
+    not fit the TCC's 4 slots together), counter unit = KB, FETCH_SIZE doubled for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md
+    prescribes.  Returns (bytes per launch | None, how)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    tot, n, t0 = 0.0, 0, time.time()
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    for ctr, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        d = tempfile.mkdtemp(prefix="vb_pmc_")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
+               "--streams", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-isolated", "--no-parity-check", "--no-pmc"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(10.0, timeout - (time.time() - t0)), env=env, cwd="/tmp")
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not fs:
+                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+            kb, launches = 0.0, 0
+            for row in csv.DictReader(open(fs[0])):
+                if row["Counter_Name"] == ctr and any(k in row["Kernel_Name"] for k in CLASS_KERNELS[cls]):
+                    kb += float(row["Counter_Value"])
+                    launches += 1
+            tot += mult * kb * 1024.0
+            n = max(n, launches)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {ctr} pass timed out"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return ((tot / n) if n else None), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
+                                       f"(--streams 1, one pass, {n} launches of the class; FETCH doubled per the gfx950 note)")
 
 
 class Telemetry:
@@ -179,6 +220,13 @@ def parse():
     ap.add_argument("--seconds", type=float, default=None, help="clip length in seconds (default 20; 120 for c5)")
     ap.add_argument("--flow-steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
+    ap.add_argument("--vocoder-precision", default="split", choices=["split", "fp32"],
+                    help="VAE + vocoder arithmetic: 'split' = fp32 I/O, every product as bf16 hi/lo pairs on the bf16 MFMA pipe (bf16x3, <= 3e-5 of "
+                         "exact fp32; the default, priced against bf16 peak / 3); 'fp32' = the literal 'fp32 vocoder' of configs[1] on "
+                         "v_mfma_f32_32x32x2_f32 (157 TFLOP/s roof)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (N = 1, default c2 command, "
+                                                          "rocprofv3 on PATH) that measure roofline.traffic in this run; fall back to the committed summary")
+    ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--scale", type=float, default=3.0)
     ap.add_argument("--streams", type=int, default=None, help="independent sub-batches per GPU, one HIP stream + host thread each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -315,6 +363,54 @@ def cpu_worker(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def checks_fixture():
+    """tests/golden/bench_c2_checks.npz (oracle/gen_bench_digest.py --checks): the oracle's replay of global clips 0 and 4 of the default
+    command for passes 0 and 1, plus its states / routing indices of clip 0, pass 0 at six Euler steps"""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "bench_c2_checks.npz")
+    return np.load(path) if os.path.exists(path) else None
+
+
+def compare_with_oracle(z, mel, g, clip, ps):
+    """one clip of one pass against the oracle's replay: latent in full (rel-L2 <= 1e-3), mel by sampled L1 (< 1e-3) and L2 digest"""
+    z_ref = torch.from_numpy(g[f"z_c{clip}_p{ps}"]).double()
+    z = z.detach().double().cpu()
+    rel = float((z - z_ref).norm() / z_ref.norm())
+    m = mel.detach().double().cpu().reshape(-1)
+    pre = f"mel_c{clip}_p{ps}_"
+    l1 = float((m[torch.from_numpy(g[pre + "idx"])] - torch.from_numpy(g[pre + "val"])).abs().mean())
+    l2 = abs(float(m.norm()) - float(g[pre + "l2"][0])) / float(g[pre + "l2"][0])
+    return {"clip": clip, "pass": ps, "ok": bool(rel <= 1e-3 and l1 < 1e-3 and l2 <= 1e-3 and bool(torch.isfinite(z).all())),
+            "latent_rel_l2": rel, "mel_l1_sampled": l1, "mel_l2_rel": l2}
+
+
+def routing_flips(w, g, scale_unused=None):
+    """teacher-forced routing check on the bench's own engine: clip 0's row of the worker's batch is replaced by the ORACLE's state x_k
+    (six Euler steps of pass 0), the network is evaluated once with the device-drawn router noise of exactly that evaluation (seed,
+    global clip, step), and the routing indices of clip 0 (both gates, both CFG branches, every block) are compared with the oracle's.
+    A differing index is caused by this evaluation's bf16 arithmetic alone.  -> flips per block, decisions per block."""
+    eng, x0 = w["eng"], w["x0"]
+    B, T = x0.shape[0], x0.shape[2]
+    cond = eng.precompute_cond(w["t5"], w["midi"], w["beats"], T)
+    depth = int(g["tf_routes_0"].shape[0])
+    flips = [0] * depth
+    decisions = 0
+    for k in [int(v) for v in g["tf_steps"]]:
+        x = x0.clone()
+        x[0] = torch.from_numpy(g[f"tf_x_{k}"][0]).to(x.device)
+        t_idx = torch.full((2 * B,), int(g[f"tf_tidx_{k}"][0]), dtype=torch.long)
+        _, r = eng.forward(x, t_idx, cond, seed=SEED, clip_base=w["clip_base"], nfe=k, return_routes=True)
+        r = r.cpu().numpy()                               # [depth][gate][2*B*T]: cond rows then uncond rows
+        ref = g[f"tf_routes_{k}"].astype("int32")         # [depth][gate][2*T]
+        mine = __import__("numpy").concatenate([r[:, :, 0:T], r[:, :, B * T:B * T + T]], axis=2)
+        for i in range(depth):
+            flips[i] += int((mine[i] != ref[i]).sum())
+        decisions += 2 * 2 * T
+    return {"per_block": flips, "decisions_per_block": decisions, "rate": sum(flips) / float(decisions * depth),
+            "what": "teacher-forced on the oracle's states of clip 0, pass 0 at Euler steps " + ",".join(str(int(v)) for v in g["tf_steps"]) +
+                    "; both gates x both CFG branches x 752 tokens per step and block"}
+
+
 def parity_check(z0, mel0, fixture="bench_clip0.npz"):
     """clip 0 of the first timed pass (bf16 production precision, router noise drawn on the device) against the oracle's replay of
     exactly that clip (tests/golden/bench_clip0*.npz, written by oracle/gen_bench_digest.py from the CPU oracle + the host
@@ -396,6 +492,10 @@ def main():
         dist.all_reduce(seen)                      # every rank reports in over the data-path backend (RCCL unless one-device test)
         assert int(seen.item()) == world
     log("weights ready; packing")
+    if args.vocoder_precision == "fp32":
+        for cls in (2, 3):
+            nm, bd, _ = CLASSES[cls]
+            CLASSES[cls] = (nm.replace("split-bf16 (bf16x3) MFMA", "fp32 MFMA (v_mfma_f32_32x32x2_f32)").replace("bf16x3 MFMA", "f32 MFMA"), bd, MFMA_F32_TF)
     ctx = Context(device)
     S = max(1, args.streams)
     B = args.batch
@@ -407,10 +507,12 @@ def main():
     def make_worker(nclips, clip_base, share=None):
         eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision, share=share)
         inp = clip_batch(nclips, T_lat, L_CTX, clip0=clip_base, seed=SEED)
-        return dict(eng=eng, vae=build_vae_decoder(ctx, sds[1]), voc=build_hifigan(ctx, sds[2], hcfg.as_hparams()),
+        return dict(eng=eng, vae=build_vae_decoder(ctx, sds[1], precision=args.vocoder_precision),
+                    voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=args.vocoder_precision),
                     x0=inp["x_latent"].to(device), t5c=inp["t5_cond"].to(device), t5u=inp["t5_uncond"].to(device),
                     t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
-                    beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=clip_base, wav=None, z0=None, mel0=None)
+                    beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=clip_base, wav=None, z0=None, mel0=None,
+                    kept={}, nclips=nclips)
 
     # S independent sub-batches, each with its own engine handle (shared packed weights), on its own HIP stream driven by its own
     # host thread: kernels of different sub-batches overlap on the GPU and fill each other's tile-quantisation tails.
@@ -431,9 +533,26 @@ def main():
             w["wav"] = w["voc"].run(mel)
         if k == 0:
             w["z0"], w["mel0"] = z[:1], mel[:1]
+        if k in keep_passes:
+            # latents / mels of this pass stay resident (a few MB) and are verified AFTER the timed region: every clip the fixture covers
+            # (global clips 0 and 4 = the first clip of each sub-batch) on the first pass, the first replay and the last pass
+            w["kept"][k] = (z, mel)
+
+    cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    pinned = {}
 
     def run_worker(w, ks):
         torch.cuda.set_device(device)           # a new host thread starts on device 0: bind it to this rank's GPU
+        si = next((i for i, ww in enumerate(workers) if ww is w), 0)
+        if len(cores) >= world * S and hasattr(os, "sched_setaffinity"):
+            # one core per (rank, stream) host thread, all distinct on the box: the launch threads of 8 ranks x 2 streams must not
+            # migrate onto each other (pid 0 = the calling thread)
+            try:
+                core = cores[(local * S + si) % len(cores)] if world > 1 else cores[si % len(cores)]
+                os.sched_setaffinity(0, {core})
+                pinned[si] = core
+            except OSError:
+                pass
         with torch.cuda.stream(w["stream"]):
             for k in ks:
                 one_pass(w, k)
@@ -456,6 +575,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    keep_passes = {0, 1, args.steps - 1}
     lib = L.load()
     torch.cuda.synchronize()
     log(f"engines built ({S} stream(s) x {Bs} clips of {clip_seconds:.1f} s, E={args.experts}); warmup")
@@ -476,10 +596,11 @@ def main():
         torch.cuda.synchronize()
     assert all(torch.isfinite(w["wav"]).all() for w in workers)
 
-    # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every 5th launch of each class bracketed by
+    # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every launch of each class bracketed by
     # HIP events on the launch stream.  This is the kernel-quality figure (roofline.frac): in the timed region below two
     # sub-batches share the CUs, so a launch's event-bracketed duration includes the other stream's kernels.
-    EVERY = 5            # coprime with the launches per block, so the sample walks over every kernel of a class
+    EVERY = 1            # every launch of the isolated pass is bracketed (a stride that divides the launches per network evaluation - 5
+                         # against 4 x 6 + 1 = 25 GEMM-class launches once the routed w2 became one launch - samples a biased subset)
     table, dominant = [], 0
     if not args.no_isolated:
         w = workers[0] if S == 1 else make_worker(B, rank * B, share=workers[0]["eng"])
@@ -518,9 +639,13 @@ def main():
         run_passes(list(range(args.steps)))
         barrier()
         elapsed = time.perf_counter() - t0
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [1e3 * float(v.item()) / args.steps for v in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     log(f"timed region: {elapsed:.3f}s")
@@ -539,6 +664,44 @@ def main():
         if fixture:
             parity = parity_check(workers[0]["z0"], workers[0]["mel0"], fixture)
             log(f"parity vs oracle digest: {parity}")
+        # ---- everything the timed region produced that an oracle fixture covers (default command only): the first clip of EVERY
+        # sub-batch / stream (global clips 0 and 4), on the first timed pass (graph replay #1 of this seed), on pass 1 (a replay with
+        # another seed) and - when the last pass is neither - the last pass bitwise against an EAGER run of the same seed; plus the
+        # teacher-forced routing-flip count per block.  A failure anywhere fails the run (exit code 3).
+        g = checks_fixture() if fixture == "bench_clip0.npz" else None
+        if parity is not None and g is not None:
+            rows, finite = [], True
+            for w in workers:
+                for ps, (z, mel) in sorted(w["kept"].items()):
+                    finite = finite and bool(torch.isfinite(z).all()) and bool(torch.isfinite(mel).all())
+                    if ps not in (0, 1):
+                        continue
+                    for c in (0, 4):
+                        r = c - w["clip_base"]
+                        if 0 <= r < w["nclips"]:
+                            rows.append(compare_with_oracle(z[r:r + 1], mel[r:r + 1], g, c, ps))
+            last = args.steps - 1
+            replay_eq = None
+            if last not in (0, 1) and all(w["eng"].graphs() for w in workers):
+                replay_eq = True
+                for w in workers:
+                    with torch.cuda.stream(w["stream"]):
+                        cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_lat, persistent=True)
+                        z_e, _ = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + last, clip_base=w["clip_base"], return_traj=True)
+                    torch.cuda.synchronize()
+                    replay_eq = replay_eq and bool(torch.equal(z_e, w["kept"][last][0]))
+            with torch.cuda.stream(workers[0]["stream"]):
+                flips = routing_flips(workers[0], g)
+            torch.cuda.synchronize()
+            flips_ok = flips["rate"] <= 2e-4
+            parity["verified"] = {"clips_x_passes": rows, "all_outputs_finite": finite,
+                                  "last_pass": ("pass %d is covered by the oracle fixture" % last) if last in (0, 1) else
+                                               {"pass": last, "graph_replay_equals_eager_bitwise": replay_eq},
+                                  "against": "tests/golden/bench_c2_checks.npz (oracle/gen_bench_digest.py --checks)"}
+            parity["routing_flips"] = flips
+            parity["ok"] = bool(parity["ok"] and finite and all(r["ok"] for r in rows) and replay_eq is not False and flips_ok)
+            log(f"verified {len(rows)} clip x pass outputs against the oracle: " + ", ".join(f"c{r['clip']}p{r['pass']} {r['latent_rel_l2']:.1e}" for r in rows) +
+                f"; finite {finite}; last-pass replay == eager: {replay_eq}; routing flips per block {flips['per_block']} of {flips['decisions_per_block']}")
 
     if rank == 0:
         name, bound, peak = CLASSES[dominant]
@@ -547,7 +710,16 @@ def main():
         achieved = iso["tflops"] if iso else conc
         # the committed PMC passes were taken on the default command (c2, 8 clips): for any other workload the per-launch figure does not apply
         pmc_applies = args.workload == "c2" and B == 8 and args.experts == 4 and abs(clip_seconds - 20.0) < 1e-9
-        traffic, traffic_file = pmc_traffic(dominant) if pmc_applies else (None, None)
+        traffic, traffic_file, traffic_how = None, None, None
+        if pmc_applies and world == 1 and not args.no_pmc:
+            log("PMC traffic passes (rocprofv3 child runs)")
+            traffic, traffic_how = pmc_traffic_live(dominant, args.pmc_timeout)
+            log(f"traffic: {traffic} ({traffic_how})")
+        if traffic is None and pmc_applies:
+            live_why = traffic_how
+            traffic, traffic_file = pmc_traffic(dominant)
+            traffic_how = (f"file: {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per the gfx950 note"
+                           + (f"; live measurement unavailable: {live_why}" if live_why else "") + ")") if traffic else live_why
         total_mel_s = world * B * clip_seconds * args.steps
         wl = {"c2": f"{B} x {clip_seconds:.0f} s clips per GPU (T_lat={T_lat}, T_mel={T_mel}, 24 kHz)",
               "c3": f"Band-MoE stress: {B} x {clip_seconds:.0f} s clips per GPU, num_experts={args.experts} ({2 * B * T_lat} token rows per evaluation)",
@@ -559,7 +731,9 @@ def main():
             "unit": "mel-s/s",
             "n_gpus": world,
             "ranks": {"world": world, "backend": ("gloo (VB_BENCH_ONE_DEVICE functional test)" if one_device else "nccl (RCCL)") if world > 1 else None,
-                      "weight_broadcast_ms": bcast_ms, "weight_broadcast_bytes": bcast_bytes, "collectives_in_timed_region": 0},
+                      "weight_broadcast_ms": bcast_ms, "weight_broadcast_bytes": bcast_bytes,
+                      "weight_broadcast_gbps": (bcast_bytes / (bcast_ms * 1e-3) / 1e9) if bcast_ms else None,
+                      "per_rank_ms": per_rank_ms, "host_thread_cores_rank0": pinned, "collectives_in_timed_region": 0},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -567,10 +741,14 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("bf16 DiT (fp32 accumulate)" if args.precision == "bf16" else "bf16x3 split DiT") +
-                     " + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32",
+                     (" + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32" if args.vocoder_precision == "split" else
+                      " + fp32 VAE/vocoder (v_mfma_f32_32x32x2_f32, exact fp32 products)"),
             "data": "synthetic (seeded PRNG clips, random-init checkpoints of the configured architecture)",
             "config": {"workload": wl + f", {args.flow_steps} Euler steps x 2 NFE (CFG scale {args.scale}), Band-MoE E={args.experts}, "
-                                        "VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml",
+                                        "VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml; VAE / vocoder arithmetic: " +
+                                        ("split-bf16 (bf16x3 products, fp32 I/O and accumulation, <= 3e-5 of exact fp32; `--vocoder-precision fp32` "
+                                         "runs the literal fp32 kernels)" if args.vocoder_precision == "split" else "exact fp32 (f32 MFMA)"),
+                       "vocoder_precision": args.vocoder_precision,
                        "baseline_config": {"c2": "configs[1]", "c3": "configs[2]", "c5": "configs[4]"}[args.workload],
                        "clips_per_gpu": B, "clip_seconds": clip_seconds, "flow_steps": args.flow_steps, "precision": args.precision, "experts": args.experts,
                        "sampler_loop": ("hipGraph replay (%d graph(s) on rank 0)" % sum(w["eng"].graphs() for w in workers))
@@ -580,14 +758,12 @@ def main():
             "device": {"name": torch.cuda.get_device_name(device), "clocks_during_timed_region": tele.summary(device)},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "how": ("dominant class = largest GPU time per pass; achieved = algorithmic flops of its event-timed launches / their "
-                                 "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 5th "
+                                 "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every "
                                  "launch bracketed by HIP events on the launch stream)") if iso else "timed-region launches (no isolated pass)",
                          "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
                          "traffic": traffic,
-                         "traffic_source": (f"file: {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per "
-                                            "the gfx950 note; PMC cannot be read in-process)") if traffic else
-                                           ("none for this workload: the committed PMC passes (profiles/r*_pmc_summary.json) are of the default c2 command"
-                                            if not pmc_applies else None),
+                         "traffic_source": traffic_how if pmc_applies else
+                                           "none for this workload: the PMC passes cover the default c2 command only",
                          "algorithmic_bytes_per_launch": (iso["algorithmic_mb_per_launch"] * 1e6) if iso else None,
                          "timed_region": ({"achieved": conc, "frac": conc / peak, "avg_launch_us": (1e3 * ms / nt) if nt else None,
                                            "launches_per_step": n / max(args.steps, 1), "timed_launches": nt,

@@ -40,6 +40,12 @@ int vb_ctx_create(int device, vb_ctx** out);
 int vb_ctx_destroy(vb_ctx* ctx);
 const char* vb_last_error(void);
 int vb_abi_version(void);
+/* sha256 (hex) over the library's sources, the public header and the compile flags it was built from; versband_amd/_lib.py compares
+ * it with the sources on disk so a stale binary is never run (struct layouts may have moved), and loads a prebuilt library as it is
+ * when no sources are shipped beside it */
+const char* vb_source_digest(void);
+/* 1 when built with -DVB_EXPERIMENTS (ablation instances and the measured-slower kernels of DESIGN.md section 5; never shipped) */
+int vb_has_experiments(void);
 
 /* HIP-event timing of one kernel class inside a region (bench.py roofline): bit 0 = bf16 GEMM,
  * bit 1 = attention, bit 2 = conv1d, bit 3 = fused ResBlock pair.  Events are recorded on the launch stream around every launch of

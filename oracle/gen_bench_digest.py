@@ -9,6 +9,11 @@ compare the HIP path's bf16 production output with it at north_star's tolerances
     python oracle/gen_bench_digest.py            # ~1-2 min of CPU: configs[1] (E = 4) -> tests/golden/bench_clip0.npz
     python oracle/gen_bench_digest.py --experts 8   # configs[2] (Band-MoE stress, E = 8) -> tests/golden/bench_clip0_e8.npz
     python oracle/gen_bench_digest.py --long        # configs[4] (120 s long-form, batch 4: clip 0 = 4 windows of 1500) -> bench_clip0_long.npz, ~5 min
+    python oracle/gen_bench_digest.py --checks      # everything bench.py's default run verifies beyond clip 0 of pass 0 (round 3):
+                                                    # clips 0 and 4 (the first clip of each of the two sub-batches / streams) x passes 0 and 1
+                                                    # (seed 1234 and 1235: pass 1 is the first hipGraph REPLAY of the timed region), plus the
+                                                    # oracle's states x_k and routing indices of clip 0 / pass 0 at six steps for the
+                                                    # teacher-forced routing-flip count -> tests/golden/bench_c2_checks.npz, ~10 min of CPU
 """
 import os
 import sys
@@ -71,9 +76,62 @@ def main_long():
     print("wrote", path)
 
 
+TF_STEPS = (0, 10, 20, 30, 40, 49)     # Euler steps whose oracle state + routing indices are kept for the teacher-forced flip count
+
+
+def main_checks():
+    """clip c of pass p of `python bench.py` = global clip index c, sampler seed SEED + p (bench.py:one_pass), router noise keyed by
+    (seed, global clip, evaluation index = Euler step, branch, block, gate)."""
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    dcfg, vcfg = synth.DiTConfig(num_experts=E), synth.VAEConfig()
+    sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1)
+    out = {"meta": np.array([SEED, T, L, E, STEPS], dtype=np.int64), "scale": np.float32(SCALE), "clips": np.array([0, 4], dtype=np.int64),
+           "passes": np.array([0, 1], dtype=np.int64), "tf_steps": np.array(TF_STEPS, dtype=np.int64)}
+    for clip in (0, 4):
+        inp = clip_batch(1, T, L, clip0=clip, seed=SEED)
+        cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
+        cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], inp["midi"], inp["beats"], T)
+        for ps in (0, 1):
+            seed = SEED + ps
+            tf = clip == 0 and ps == 0
+            t_span, idx = ref_cpu.t_index_table(STEPS + 1)
+            x = inp["x_latent"].clone()
+            t = t_span[0]
+            for k in range(STEPS):                      # ref_cpu.sample_cfg unrolled (same bookkeeping) so states and routes can be kept
+                dt = t_span[k + 1] - t
+                ti = torch.full((1,), int(idx[k]), dtype=torch.long)
+                nz = [device_noise(seed, clip, k, br, E) for br in (0, 1)]
+                if tf and k in TF_STEPS:
+                    out[f"tf_x_{k}"] = x.numpy().copy()
+                    e_c, aux_c = ref_cpu.dit_forward(sd, x, ti, cc, nz[0], return_aux=True)
+                    e_u, aux_u = ref_cpu.dit_forward(sd, x, ti, cu, nz[1], return_aux=True)
+                    r = np.zeros((DEPTH, 2, 2 * T), dtype=np.int8)     # [block][gate: caption, acoustic][cond rows then uncond rows]
+                    for br, aux in ((0, aux_c), (1, aux_u)):
+                        for i in range(DEPTH):
+                            r[i, 0, br * T:(br + 1) * T] = aux[f"ic{i}"].reshape(-1).numpy()
+                            r[i, 1, br * T:(br + 1) * T] = aux[f"ia{i}"].reshape(-1).numpy()
+                    out[f"tf_routes_{k}"] = r
+                    out[f"tf_tidx_{k}"] = np.array([int(idx[k])], dtype=np.int64)
+                else:
+                    e_c = ref_cpu.dit_forward(sd, x, ti, cc, nz[0])
+                    e_u = ref_cpu.dit_forward(sd, x, ti, cu, nz[1])
+                x = x + dt * (e_u + SCALE * (e_c - e_u))
+                t = t + dt
+            mel = ref_cpu.vae_decode(sdv, x)
+            out[f"z_c{clip}_p{ps}"] = x.numpy()
+            out.update(digest(mel, f"mel_c{clip}_p{ps}_"))
+            print(f"clip {clip} pass {ps} done", flush=True)
+    path = os.path.join(ROOT, "tests", "golden", "bench_c2_checks.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 def main():
     if "--long" in sys.argv:
         return main_long()
+    if "--checks" in sys.argv:
+        return main_checks()
     E = int(sys.argv[sys.argv.index("--experts") + 1]) if "--experts" in sys.argv else 4
     torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     dcfg, vcfg = synth.DiTConfig(num_experts=E), synth.VAEConfig()

@@ -51,3 +51,17 @@ def test_no_gpu_means_loud_failure():
     from versband_amd.engine import Context
     with pytest.raises(L.VersbandError):
         Context("cuda:0")
+
+
+def test_library_carries_the_digest_of_its_sources(monkeypatch):
+    """the loader's stale check reads the digest compiled into the .so: current after a build; a library whose digest
+    differs from the tree is refused - not silently rebuilt - when build_if_missing is False"""
+    import pytest
+    from versband_amd import build as B
+    lib = L.load()
+    assert B.library_digest() == B.source_digest() == lib.vb_source_digest().decode()
+    assert lib.vb_has_experiments() in (0, 1)
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(B, "source_digest", lambda: "0" * 64)
+    with pytest.raises(L.VersbandError, match="stale"):
+        L.load(build_if_missing=False)

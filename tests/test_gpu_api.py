@@ -159,3 +159,31 @@ def test_host_restatement_of_the_device_noise_stream():
             ref = -np.log(e.astype(np.float64))
             err = np.abs(g[br, b].numpy() - ref) / np.maximum(1.0, np.abs(ref))
             assert err.max() < 2e-6, (br, b, float(err.max()))
+
+
+def test_index_range_check_is_not_skipped_for_converted_inputs():
+    """the range check of midi / beats was cached on the address of converted TEMPORARIES (CPU / int32 inputs), which the
+    caching allocator recycles - a bad track arriving after a good one of the same size skipped the check and embed_t_kernel read
+    out of bounds.  Converted inputs are now checked on every call; resident int64 tracks are cached with a reference held."""
+    from versband_amd.engine import Context, DiTEngine
+    cfg = synth.DiTConfig()
+    eng = DiTEngine(Context("cuda:0"), cfg, synth.make_state_dict(synth.dit_shapes(cfg), SEED), precision="bf16")
+    B, T, Lc = 1, 64, 16
+    inp = clip_batch(B, T, Lc)
+    t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]])
+    for conv in (lambda t: t.to(torch.int32), lambda t: t.clone()):          # CPU int32, CPU int64: both become device temporaries
+        eng.precompute_cond(t5, conv(inp["midi"]), conv(inp["beats"]), T)
+        torch.cuda.synchronize()
+        bad = conv(inp["midi"]).clone()
+        bad.view(-1)[3] = 1000
+        with pytest.raises(IndexError):
+            eng.precompute_cond(t5, bad, conv(inp["beats"]), T)
+    # resident tracks: checked once, then served from the cache until they are modified in place
+    midi, beats = inp["midi"].to("cuda:0").reshape(B, -1).contiguous(), inp["beats"].to("cuda:0").reshape(B, -1).contiguous()
+    eng.precompute_cond(t5, midi, beats, T)
+    n = len(eng._checked)
+    eng.precompute_cond(t5, midi, beats, T)
+    assert len(eng._checked) == n >= 1
+    midi[0, 5] = 777
+    with pytest.raises(IndexError):
+        eng.precompute_cond(t5, midi, beats, T)

@@ -40,3 +40,16 @@ def test_two_ranks_one_command_match_single_process(tmp_path):
         a, b = np.load(os.path.join(d1, n)), np.load(os.path.join(d2, n))
         assert a.shape == b.shape and np.isfinite(a).all()
         assert np.array_equal(a, b), f"{n}: rank-sharded output differs from the single-process output (max |d| = {np.abs(a - b).max():.3e})"
+
+
+def test_c4_rank_shape_under_a_process_group():
+    """configs[3]'s PER-RANK shape - 8 clips per rank as 2 concurrent sub-batches on 2 streams, the sampler loops replayed as
+    hipGraphs - run by two ranks under a process group (one device, gloo): the JSON line must carry both ranks' timings, the
+    broadcast rate, and the oracle verification of rank 0's clips."""
+    out = _bench(["--gpus", "2", "--workload", "c2", "--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-isolated",
+                  "--no-pmc"], {"VB_BENCH_ONE_DEVICE": "1"}, timeout=1500)
+    assert out["n_gpus"] == 2 and out["config"]["clips_per_gpu"] == 8 and out["config"]["streams_per_gpu"] == 2
+    assert len(out["ranks"]["per_rank_ms"]) == 2 and all(v > 0 for v in out["ranks"]["per_rank_ms"])
+    assert out["ranks"]["weight_broadcast_gbps"] > 0 and out["ranks"]["collectives_in_timed_region"] == 0
+    assert "hipGraph replay" in out["config"]["sampler_loop"]
+    assert out["parity_check"]["ok"] is True and len(out["parity_check"]["verified"]["clips_x_passes"]) == 4

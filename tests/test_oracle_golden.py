@@ -229,3 +229,20 @@ def test_melnet_dft_weights_as_hop_block_convolution(golden_dir):
     # short window: centred zero-padding like torch.stft
     w = M.hann_window(800, 1280)
     assert w[:240].max() == 0.0 and w[1040:].max() == 0.0 and abs(w[240 + 400] - 1.0) < 1e-6
+
+
+def test_bench_checks_fixture_is_consistent_with_the_clip0_fixture(golden_dir):
+    """tests/golden/bench_c2_checks.npz (oracle/gen_bench_digest.py --checks): its (clip 0, pass 0) entry is the same oracle replay as
+    bench_clip0.npz, bit for bit; every (clip, pass) entry and every teacher-forced step is present and finite"""
+    g = _load(golden_dir, "bench_c2_checks.npz")
+    g0 = _load(golden_dir, "bench_clip0.npz")
+    assert np.array_equal(g["z_c0_p0"], g0["z"]) and np.array_equal(g["mel_c0_p0_val"], g0["mel_val"])
+    for c in (0, 4):
+        for p in (0, 1):
+            z = g[f"z_c{c}_p{p}"]
+            assert z.shape == (1, 20, 752) and np.isfinite(z).all() and g[f"mel_c{c}_p{p}_idx"].shape == (256,)
+    assert not np.array_equal(g["z_c0_p0"], g["z_c0_p1"]) and not np.array_equal(g["z_c0_p0"], g["z_c4_p0"])
+    for k in g["tf_steps"]:
+        r = g[f"tf_routes_{int(k)}"]
+        assert r.shape == (4, 2, 1504) and r.min() >= 0 and r.max() <= 3
+        assert g[f"tf_x_{int(k)}"].shape == (1, 20, 752)

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "vb_dit_workspace_bytes": (c_size_t, [C.POINTER(DitConfig), c_int, c_int, c_int, c_int]),
     "vb_dit_precompute_cond": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "vb_dit_forward": (c_int, [P, P, P, P, C.POINTER(Noise), c_int, c_int, c_int, c_int, P, P, P, P]),
+    "vb_source_digest": (C.c_char_p, []),
+    "vb_has_experiments": (c_int, []),
     "vb_euler_cfg_step": (c_int, [P, P, c_int, c_i64, c_float, c_float, c_int, P]),
     "vb_sample_cfg": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_float, C.POINTER(Noise), P, P, P]),
     "vb_sample_graphs": (c_int, [P]),
@@ -142,15 +144,24 @@ def load(build_if_missing: bool = True):
     import torch
     if torch.cuda.is_available():
         torch.cuda.init()
-    from .build import build, is_current
-    if not os.path.exists(LIB_PATH) and not build_if_missing:
-        raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
-    if not is_current():
-        # missing OR built from other sources (the digest covers csrc/ and the public header): never run a stale binary - an ABI
-        # struct mismatch would be memory corruption, not an error.  hipcc cross-compiles, so this works without a GPU too.
-        if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-            raise VersbandError(f"{LIB_PATH} is missing or stale and hipcc is not available to rebuild it")
+    from .build import build, library_digest, source_digest, sources_present
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
         build()
+    elif sources_present():
+        # never run a binary built from other sources than the ones on disk: an ABI struct mismatch would be memory corruption, not an
+        # error.  The digest travels INSIDE the library (vb_source_digest; read from the file here, before anything is mapped), so a
+        # prebuilt .so shipped without csrc/build - or without any sources: deployment image, wheel - loads as it is, and a stale
+        # one is named as such instead of being rebuilt behind the caller's back when build_if_missing is False.
+        have, want = library_digest(LIB_PATH), source_digest()
+        if have != want:
+            if not build_if_missing:
+                raise VersbandError(f"{LIB_PATH} is stale: built from sources {str(have)[:16]}..., the tree holds {want[:16]}... "
+                                    "(run `python -m versband_amd.build`)")
+            if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+                raise VersbandError(f"{LIB_PATH} is stale and hipcc is not available to rebuild it")
+            build()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 
 typedef __bf16 bf16_t;
@@ -78,19 +79,28 @@ struct VbTune {
     int router_tpw = 0, gemm_small = 11, gemm_small_tiles = 300, gemm_tile = -1, gemm_variant = 1, gemm_ablate = 0, gemm_nchunk = 0, gemm_p8 = -1, gemm_p8_mask = 0, gemm_p8_direct = 0;
     int conv_cfg = 0, conv_ablate = 0, attn_ablate = 0, attn_variant = -1;
     bool conv_direct_epi = false, gate_unfolded = false, stem_f32 = false, band_unfused = false, moe_unfused = false, score_fused = false, no_graph = false;
+    int w2_pair = 1;
 };
 const VbTune& vb_tune();
+unsigned vb_tune_generation();      // bumped by vb_tune_reload(): anything that bakes knob-dependent kernel choices in (captured graphs) keys on it
 
 // "first launch of this kernel on the CURRENT device": per-device once-flags for hipFuncSetAttribute (a process normally owns one
 // GPU, but nothing here may silently depend on that)
-struct OnceFlags { bool seen[64] = {}; };
-static inline bool vb_first_use_on_device(OnceFlags& f) {
+// Several host threads (one per stream) may reach their first launch of a kernel together: exactly one of them sets the
+// attribute (compare-exchange), the others wait the few microseconds until it is set - nobody launches before it is.
+struct OnceFlags { std::atomic<int> state[64] = {}; };      // per device: 0 = untouched, 1 = being set, 2 = done
+static inline void vb_set_max_lds_once(OnceFlags& f, const void* kernel, int bytes) {
     int d = 0;
     (void)hipGetDevice(&d);
     d &= 63;
-    if (f.seen[d]) return false;
-    f.seen[d] = true;
-    return true;
+    if (f.state[d].load(std::memory_order_acquire) == 2) return;
+    int expect = 0;
+    if (f.state[d].compare_exchange_strong(expect, 1, std::memory_order_acq_rel)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        f.state[d].store(2, std::memory_order_release);
+        return;
+    }
+    while (f.state[d].load(std::memory_order_acquire) != 2) {}
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

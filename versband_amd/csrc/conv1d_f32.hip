@@ -537,12 +537,15 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg_x3(const ConvDev& d, int n_count, int B, hipStream_t st) {
     dim3 grid(cdiv(n_count, WN * TN * 32), cdiv(d.Co, WM * TM * 32), B * d.phases);
+#ifdef VB_EXPERIMENTS      // ablation instances exist in the experiments build only (tools/conv_bench.py)
     const int abl = vb_tune().conv_ablate;
     if (abl == 1) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, d);
     else if (abl == 2) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, d);
     else if (abl == 3) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 3>), grid, dim3(256), 0, st, d);
     else if (abl == 4) hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 4>), grid, dim3(256), 0, st, d);
-    else hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 0>), grid, dim3(256), 0, st, d);
+    else
+#endif
+    hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 0>), grid, dim3(256), 0, st, d);
 }
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg_xt(const ConvDev& d, int n_count, int B, hipStream_t st) {

@@ -431,29 +431,35 @@ int launch_router_top1(const float* logits, const float* gumbel, int N, int E, i
 // `counts` lives right behind perm's 2N entries (perm buffers are sized 2N + nblk*2E + 64 by the engine).
 // ---------------------------------------------------------------------------
 #define BK_T 256
-__global__ void __launch_bounds__(BK_T) bucket_count_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
+#define BK_G 32          // groups a launch can rank: 2E expert groups (+ E*E (caption, acoustic) PAIR groups when E <= 4)
+// Pair mode (pair_off != null, E <= 4): the same launches also bucket the tokens by their (caption expert, acoustic expert) PAIR -
+// group 2E + c*E + a - for the single-launch w2 product (moe_w2_pair_kernel): pair_tok[p] = token of pair slot p, pair_rows[p] =
+// (caption slot, acoustic slot) of that token = the two rows of the routed hidden tensor the K-concatenated product gathers.
+__global__ void __launch_bounds__(BK_T) bucket_count_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E, int G,
                                                            int* counts) {
-    __shared__ int wc[4][32];
+    __shared__ int wc[4][BK_G];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x * BK_T + tid;
     const int gc = n < N ? ic[n] : -1, ga = n < N ? E + ia[n] : -1;
-    for (int g = 0; g < 2 * E; ++g) {
-        const unsigned long long m = __ballot(g < E ? (gc == g) : (ga == g));
+    const int gp = n < N ? 2 * E + gc * E + (ga - E) : -1;
+    for (int g = 0; g < G; ++g) {
+        const unsigned long long m = __ballot(g < E ? (gc == g) : (g < 2 * E ? (ga == g) : (gp == g)));
         if (lane == 0) wc[wave][g] = __popcll(m);
     }
     __syncthreads();
-    if (tid < 2 * E) counts[blockIdx.x * 2 * E + tid] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
+    if (tid < G) counts[blockIdx.x * G + tid] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
 }
-__global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
-                                                           const int* __restrict__ counts, int nblk, int* group_off, int* perm) {
-    __shared__ int base[32];        // slot of this block's first token of every group
-    __shared__ int wc[4][32];
+__global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E, int G,
+                                                           const int* __restrict__ counts, int nblk, int* group_off, int* perm,
+                                                           int* pair_off, int* pair_tok, int2* pair_rows) {
+    __shared__ int base[BK_G];        // slot of this block's first token of every group
+    __shared__ int wc[4][BK_G];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = 2 * E;
+    const int G2 = 2 * E;
     // group start = sum of all earlier groups' totals; + this group's tokens in earlier blocks.  The counts table is
     // summed by the whole block (thread = (row-of-counts, group)), not by G serial threads.
-    __shared__ int tot[32], bef[32];
-    if (tid < 32) { tot[tid] = 0; bef[tid] = 0; }
+    __shared__ int tot[BK_G], bef[BK_G];
+    if (tid < BK_G) { tot[tid] = 0; bef[tid] = 0; }
     __syncthreads();
     {
         const int g = tid % G;
@@ -467,23 +473,31 @@ __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restric
     }
     __syncthreads();
     if (tid < G) {
+        // expert groups count slots from 0 (caption groups, then acoustic groups: 2N slots); pair groups count pair slots from 0
         int before_groups = 0;
-        for (int g = 0; g < tid; ++g) before_groups += tot[g];
+        for (int g = (tid < G2 ? 0 : G2); g < tid; ++g) before_groups += tot[g];
         base[tid] = before_groups + bef[tid];
         if (blockIdx.x == 0) {
-            group_off[tid] = before_groups;
-            if (tid == G - 1) group_off[G] = before_groups + tot[tid];
+            if (tid < G2) {
+                group_off[tid] = before_groups;
+                if (tid == G2 - 1) group_off[G2] = before_groups + tot[tid];
+            } else {
+                pair_off[tid - G2] = before_groups;
+                if (tid == G - 1) pair_off[G - G2] = before_groups + tot[tid];
+            }
         }
     }
     const int n = blockIdx.x * BK_T + tid;
     const int gc = n < N ? ic[n] : -1, ga = n < N ? E + ia[n] : -1;
-    int rank_c = 0, rank_a = 0;
+    const int gp = (n < N && G > G2) ? G2 + gc * E + (ga - E) : -1;
+    int rank_c = 0, rank_a = 0, rank_p = 0;
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int g = 0; g < G; ++g) {
-        const unsigned long long m = __ballot(g < E ? (gc == g) : (ga == g));
+        const unsigned long long m = __ballot(g < E ? (gc == g) : (g < G2 ? (ga == g) : (gp == g)));
         if (lane == 0) wc[wave][g] = __popcll(m);
         if (g == gc) rank_c = __popcll(m & lower);
         if (g == ga) rank_a = __popcll(m & lower);
+        if (g == gp) rank_p = __popcll(m & lower);
     }
     __syncthreads();
     if (n < N) {
@@ -491,18 +505,29 @@ __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restric
         for (int w = 0; w < wave; ++w) { pc += wc[w][gc]; pa += wc[w][ga]; }
         perm[pc] = n;
         perm[pa] = n;
+        if (gp >= 0) {
+            int pp = base[gp] + rank_p;
+            for (int w = 0; w < wave; ++w) pp += wc[w][gp];
+            pair_tok[pp] = n;
+            pair_rows[pp] = make_int2(pc, pa);
+        }
     }
 }
-int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st) {
+int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off, int* pair_tok,
+                  int* pair_rows) {
     if (E > 16) VB_FAIL(VB_E_INVALID, "bucket: E=%d > 16", E);
+    const bool pairs = pair_off != nullptr;
+    const int G = 2 * E + (pairs ? E * E : 0);
+    if (G > BK_G) VB_FAIL(VB_E_INVALID, "bucket: %d groups > %d (pair mode needs E <= 4)", G, BK_G);
     const int nblk = cdiv(N, BK_T);
     int* counts = perm + 2 * (size_t)N;          // scratch tail of the perm buffer (see bucket_scratch_ints)
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, counts);
-    hipLaunchKernelGGL(bucket_place_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, counts, nblk, group_off, perm);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
+    hipLaunchKernelGGL(bucket_place_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts, nblk, group_off, perm, pair_off, pair_tok,
+                       reinterpret_cast<int2*>(pair_rows));
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
-int bucket_scratch_ints(int N, int E) { return cdiv(N, BK_T) * 2 * E + 64; }
+int bucket_scratch_ints(int N, int E) { return cdiv(N, BK_T) * BK_G + 64; }
 
 // element (row n = (branch*B + b)*T + t, e) of stream (seed, clip_base + b, nfe, branch, block, gate)
 __global__ void fill_gumbel_kernel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base,

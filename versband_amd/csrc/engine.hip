@@ -6,6 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -16,38 +19,75 @@ thread_local char g_vb_err[512] = "";
 
 // ---- tuning knobs ---------------------------------------------------------------------------
 static VbTune g_tune;
-static bool g_tune_loaded = false;
+static std::atomic<bool> g_tune_loaded{false};
+static std::atomic<unsigned> g_tune_gen{0};
 static std::mutex g_tune_mu;
 static int env_int(const char* k, int dflt) { const char* v = getenv(k); return (v && *v) ? atoi(v) : dflt; }
 static void tune_load() {
     VbTune t;
+    // product knobs: result-preserving selections the tests flip to compare both forms, plus VB_ATTN_DEFER / VB_NO_GRAPH
     t.router_tpw = env_int("VB_ROUTER_TPW", 0);
     if (const char* v = getenv("VB_ATTN_DEFER")) t.attn_defer_thr = (float)atof(v);     // log2 units; 0 = exact running maximum
     t.gemm_small = env_int("VB_GEMM_SMALL", 11); t.gemm_small_tiles = env_int("VB_GEMM_SMALL_TILES", 300);
-    t.gemm_tile = env_int("VB_GEMM_TILE", -1); t.gemm_variant = env_int("VB_GEMM_VARIANT", 1); t.gemm_ablate = env_int("VB_GEMM_ABLATE", 0);
-    t.gemm_nchunk = env_int("VB_GEMM_NCHUNK", 0); t.gemm_p8 = env_int("VB_GEMM_P8", -1);
-    t.gemm_p8_mask = env_int("VB_GEMM_P8_MASK", 0); t.gemm_p8_direct = env_int("VB_GEMM_P8_DIRECT", 0);
-    t.conv_cfg = env_int("VB_CONV_CFG", 0); t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
-    t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
+    t.gemm_tile = env_int("VB_GEMM_TILE", -1);
+    t.conv_cfg = env_int("VB_CONV_CFG", 0);
     t.conv_direct_epi = getenv("VB_CONV_DIRECT_EPI") != nullptr;
     t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
     t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr; t.moe_unfused = getenv("VB_MOE_UNFUSED") != nullptr;
-    t.score_fused = getenv("VB_SCORE_FUSED") != nullptr;
+    t.w2_pair = env_int("VB_W2_PAIR", 1);
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
+#ifdef VB_EXPERIMENTS
+    // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
+    t.gemm_variant = env_int("VB_GEMM_VARIANT", 1); t.gemm_ablate = env_int("VB_GEMM_ABLATE", 0);
+    t.gemm_nchunk = env_int("VB_GEMM_NCHUNK", 0); t.gemm_p8 = env_int("VB_GEMM_P8", -1);
+    t.gemm_p8_mask = env_int("VB_GEMM_P8_MASK", 0); t.gemm_p8_direct = env_int("VB_GEMM_P8_DIRECT", 0);
+    t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
+    t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
+    t.score_fused = getenv("VB_SCORE_FUSED") != nullptr;
+#endif
     g_tune = t;
-    g_tune_loaded = true;
+    g_tune_gen.fetch_add(1, std::memory_order_relaxed);
+    g_tune_loaded.store(true, std::memory_order_release);
 }
 const VbTune& vb_tune() {
-    if (!g_tune_loaded) {
+    if (!g_tune_loaded.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lk(g_tune_mu);
-        if (!g_tune_loaded) tune_load();
+        if (!g_tune_loaded.load(std::memory_order_relaxed)) tune_load();
     }
     return g_tune;
 }
+unsigned vb_tune_generation() { (void)vb_tune(); return g_tune_gen.load(std::memory_order_relaxed); }
+// (tools / tests only, single-threaded by contract: no launch may be in flight on another host thread while the knobs change)
 extern "C" void vb_tune_reload(void) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     tune_load();
 }
+
+// ---- roctx ranges (rocprofv3 --marker-trace): the profiler's marker library is looked up at run time, nothing links against it ----
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static std::once_flag g_roctx_once;
+static void roctx_init() {
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) return;
+        g_roctx_push = nullptr; g_roctx_pop = nullptr;
+    }
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) {
+        std::call_once(g_roctx_once, roctx_init);
+        on = g_roctx_push != nullptr;
+        if (on) (void)g_roctx_push(name);
+    }
+    ~RoctxRange() { if (on) (void)g_roctx_pop(); }
+};
 
 // ---- kernel-class profiling -----------------------------------------------------------------
 #define PROF_CLASSES 4
@@ -96,7 +136,7 @@ struct NetProgram {
 // one captured + instantiated step loop of vb_sample_cfg (hipGraph), keyed by everything the launches bake in
 struct SampleGraph {
     const void* x = nullptr; const void* cond = nullptr; const void* ws = nullptr;
-    int B = 0, nb = 0, T = 0, L = 0, n_steps = 0; float cfg_scale = 0.f;
+    int B = 0, nb = 0, T = 0, L = 0, n_steps = 0; float cfg_scale = 0.f; unsigned tune_gen = 0;
     int seen = 0;                         // calls with this key so far (the first runs eagerly, the second captures)
     bool failed = false;                  // capture was refused once (e.g. legacy default stream): stay eager
     hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
@@ -184,7 +224,7 @@ struct WsL {
     bf16_t* modA;                                                   // A operand (planes) of the adaLN tabulation GEMM
     float *temb0_s, *temb_s, *hl_s, *mod_s; int64_t* row_step;     // per-sample tables of the conditioning vectors of every step
     bf16_t *u, *q, *k, *vt, *a, *qm, *cqa, *Hs, *y, *Hf;
-    int *ic, *ia, *group_off, *perm;
+    int *ic, *ia, *group_off, *perm, *pair_off, *pair_tok, *pair_rows;
     // precompute temporaries
     float *tA, *tB, *tC, *tD, *tE, *cap_pre, *cap32, *pooled, *pooled_ln;
     bf16_t *t5p, *gel, *capp, *yp;
@@ -229,6 +269,9 @@ static WsL carve_ws(void* base, const vb_dit_config& c, int B, int nb, int T, in
     o.ia = cv.take<int>(N);
     o.group_off = cv.take<int>(2 * E + 1);
     o.perm = cv.take<int>(2 * N + bucket_scratch_ints((int)N, E));
+    o.pair_off = cv.take<int>(32);
+    o.pair_tok = cv.take<int>(N);
+    o.pair_rows = cv.take<int>(2 * N);
     // precompute temporaries
     const int T_mel = 2 * T + 8;
     o.tA = cv.take<float>((size_t)B * D * T_mel);
@@ -431,9 +474,14 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         // below).  MEASURED SLOWER - 91 us against 32 + 22 at 8 clips: its mainloop runs 36 us with one 4-wave workgroup per CU and the
         // router's per-token wave-wide shuffles take 63 us without many waves per SIMD to hide them - so it is an opt-in experiment
         // (VB_SCORE_FUSED=1), kept with its test as the record.
+#ifdef VB_EXPERIMENTS
         const bool fused_router = fold && np == 1 && vb_tune().score_fused && score_router_supported(cd.NS, D, E, c.heads) &&
                                   (int64_t)Beff * cdiv(T, 64) >= 96;
+#else
+        const bool fused_router = false;
+#endif
         if (fused_router) {
+#ifdef VB_EXPERIMENTS
             ScoreRouterArgs sr;
             sr.A = u.p; sr.lda = D; sr.Bm = cd.mf[i]; sr.ldb = D; sr.bias = cd.cb[i]; sr.vw = cd.vw[i]; sr.bg = bw.bcg; sr.la = cd.la[i];
             sr.la_rows = B * T; sr.hl = hl + i * 2; sr.hl_ld = hl_ld; sr.g1 = g1; sr.g2 = g2; sr.g3 = g3; sr.Beff = Beff; sr.B = B; sr.T = T;
@@ -441,6 +489,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
             sr.seed = noise ? noise->seed : 0; sr.clip_base = noise ? noise->clip_base : 0; sr.nfe_base = noise ? noise->nfe : 0;
             sr.step = step_ptr; sr.block = i;
             VB_TRY(launch_score_router(sr, st));
+#endif
         } else {
         if (fold) {
             // caption gate, folded: scores of every token against its clip's caption keys for all heads in ONE grouped GEMM
@@ -468,7 +517,10 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
                              s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st,
                              fold ? s.y32 : nullptr, cd.NS, c.heads));
         }
-        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st));
+        // routed w2 as ONE launch over (caption, acoustic) pair buckets: bf16 mode, E*E <= 16 groups, and enough tokens that the
+        // pair tiles' padding (<= one 128-row tile per pair) stays small; otherwise the two grouped w2 launches (bit-identical)
+        const bool w2_pair = np == 1 && E * E <= 16 && H % 64 == 0 && vb_tune().w2_pair && N >= 256 * E * E;
+        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st, w2_pair ? s.pair_off : nullptr, s.pair_tok, s.pair_rows));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 1) * N, s.ia, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -479,6 +531,12 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         g.ldb = D; g.b_group_stride = (int64_t)2 * H * D; g.M = 2 * N; g.N = 2 * H; g.K = D; g.nseg = nseg; g.ngroups = 2 * E;
         g.group_off = s.group_off; g.epi = EPI_SWIGLU; g.out = Hs; g.ldc = H;
         VB_TRY(launch_gemm(g, st));
+        if (w2_pair) {
+            MoeW2PairArgs pw;
+            pw.Hs = Hs.p; pw.W2 = (const bf16_t*)bw.w2; pw.pair_off = s.pair_off; pw.pair_tok = s.pair_tok; pw.pair_rows = s.pair_rows;
+            pw.mc = s.mc; pw.ma = s.ma; pw.out = y.p; pw.N = N; pw.D = D; pw.H = H; pw.E = E;
+            VB_TRY(launch_moe_w2_pair(pw, st));
+        } else {
         // y = m_c * FFN^c(u)  (store), then y += m_a * FFN^a(u) (planes out)
         g = GemmArgs();
         g.A = Hs.p; g.a_plane = Hs.plane; g.lda = H; g.B = (const bf16_t*)bw.w2; g.b_plane = (int64_t)2 * E * D * H; g.ldb = H;
@@ -488,6 +546,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         g.B = (const bf16_t*)bw.w2 + (int64_t)E * D * H; g.group_off = s.group_off + E; g.epi = EPI_SCATTER_ADD_PLANES;
         g.y32_in = s.y32; g.row_scale = s.ma; g.out = y; g.ldc = D;
         VB_TRY(launch_gemm(g, st));
+        }
         // band experts (frequency-MoE): expert e sees only channel band e and produces only band e
         const bool band_unfused = vb_tune().band_unfused;       // tuning / A-B switch (tests compare both)
         // (a fused workgroup owns 192 tokens x one band for ~50 us whatever the batch: below ~128 workgroups - half a round of the
@@ -646,6 +705,14 @@ extern "C" {
 
 const char* vb_last_error(void) { return g_vb_err; }
 int vb_abi_version(void) { return 2; }
+// (vb_source_digest() lives in a two-line translation unit versband_amd/build.py generates: csrc/build/vb_digest.cpp)
+int vb_has_experiments(void) {
+#ifdef VB_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int vb_prof_enable(int class_mask) {
     if (class_mask && g_prof_ev.empty()) {
@@ -706,6 +773,12 @@ int vb_dit_load(vb_ctx* ctx, const vb_dit_config* cfg, const vb_dit_weights* w) 
     if (cfg->context_dim != cfg->hidden) VB_FAIL(VB_E_INVALID, "dit_load: context_dim must equal hidden_size (vocal2music_moe.py:367-373)");
     if (cfg->num_experts > 16) VB_FAIL(VB_E_INVALID, "dit_load: num_experts %d > 16", cfg->num_experts);
     if (cfg->hidden > 768) VB_FAIL(VB_E_INVALID, "dit_load: hidden %d > 768 (router register tile)", cfg->hidden);
+    // captured sampler graphs hold the OLD weight pointers and launch geometry in their kernel nodes: a (re)load drops them all
+    for (SampleGraph& g : ctx->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    ctx->graphs.clear();
     ctx->cfg = *cfg;
     ctx->w = *w;
     ctx->dit_loaded = true;
@@ -722,6 +795,7 @@ int vb_dit_precompute_cond(vb_ctx* ctx, const float* t5, const int64_t* midi, co
     if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "precompute_cond: DiT not loaded");
     if (n_branch < 1 || n_branch > 2 || B < 1) VB_FAIL(VB_E_INVALID, "precompute_cond: B=%d n_branch=%d", B, n_branch);
     VB_HIP(hipSetDevice(ctx->device));
+    RoctxRange rr("vb_dit_precompute_cond");
     return dit_precompute(ctx, t5, midi, beats, B, n_branch, T, T_mel, L, cond, ws, (hipStream_t)stream);
 }
 int vb_dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int B, int n_branch,
@@ -769,6 +843,7 @@ static int sample_steps(vb_ctx* ctx, float* x, const void* cond, int B, int n_br
         VB_TRY(launch_gemv_rows(s.temb_s, D, nullptr, 0, 1, w.hl_w, w.hl_b, n_steps, c.depth * 2, D, 0, s.hl_s, c.depth * 2, st));
     }
     for (int k = 0; k < n_steps; ++k) {
+        RoctxRange rs("euler_step");
         VB_TRY(launch_step_ctl(s.step, s.t_idx_cur, s.t_table, n_steps, Beff, k == 0, st));
         VB_TRY(dit_forward(ctx, x, s.t_idx_cur, cond, noise, k, s.step, B, n_branch, T, L, s.v, nullptr, ws, false,
                            tab ? s.mod_s + (size_t)k * Beff * MODW : nullptr, tab ? s.hl_s + (size_t)k * c.depth * 2 : nullptr, st));
@@ -784,6 +859,7 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
     if (!ctx || !ctx->dit_loaded) VB_FAIL(VB_E_STATE, "sample_cfg: DiT not loaded");
     if (n_steps < 1 || n_steps > 1024) VB_FAIL(VB_E_INVALID, "sample_cfg: n_steps=%d", n_steps);
     VB_HIP(hipSetDevice(ctx->device));
+    RoctxRange rr("vb_sample_cfg");
     hipStream_t st = (hipStream_t)stream;
     const vb_dit_config& c = ctx->cfg;
     WsL s = carve_ws(ws, c, B, n_branch, T, L);
@@ -806,7 +882,7 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
         SampleGraph* e = nullptr;
         for (SampleGraph& gph : ctx->graphs)
             if (gph.x == x && gph.cond == cond && gph.ws == ws && gph.B == B && gph.nb == n_branch && gph.T == T && gph.L == L &&
-                gph.n_steps == n_steps && gph.cfg_scale == cfg_scale) { e = &gph; break; }
+                gph.n_steps == n_steps && gph.cfg_scale == cfg_scale && gph.tune_gen == vb_tune_generation()) { e = &gph; break; }
         if (!e) {
             if (ctx->graphs.size() >= 8) {          // evict the least recently used entry
                 size_t lru = 0;
@@ -816,6 +892,7 @@ int vb_sample_cfg(vb_ctx* ctx, float* x, const void* cond, int B, int n_branch, 
                 ctx->graphs.erase(ctx->graphs.begin() + lru);
             }
             SampleGraph n; n.x = x; n.cond = cond; n.ws = ws; n.B = B; n.nb = n_branch; n.T = T; n.L = L; n.n_steps = n_steps; n.cfg_scale = cfg_scale;
+            n.tune_gen = vb_tune_generation();      // a captured graph bakes the knob-dependent kernel selection in
             ctx->graphs.push_back(n);
             e = &ctx->graphs.back();
         }
@@ -983,14 +1060,17 @@ size_t vb_net_workspace_bytes(vb_ctx* ctx, int which, int B, int T) {
 }
 int vb_vae_decode(vb_ctx* ctx, const float* z, int B, int T, float* mel, void* ws, void* stream) {
     if (!ctx) VB_FAIL(VB_E_INVALID, "vae_decode: null ctx");
+    RoctxRange rr("vb_vae_decode");
     return net_run(ctx, VB_NET_VAE, z, B, T, mel, ws, (hipStream_t)stream);
 }
 int vb_vae_encode(vb_ctx* ctx, const float* mel, int B, int T, float* moments, void* ws, void* stream) {
     if (!ctx) VB_FAIL(VB_E_INVALID, "vae_encode: null ctx");
+    RoctxRange rr("vb_vae_encode");
     return net_run(ctx, VB_NET_VAE_ENCODER, mel, B, T, moments, ws, (hipStream_t)stream);
 }
 int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream) {
     if (!ctx) VB_FAIL(VB_E_INVALID, "hifigan_forward: null ctx");
+    RoctxRange rr("vb_hifigan_forward");
     return net_run(ctx, VB_NET_VOCODER, mel, B, T, wav, ws, (hipStream_t)stream);
 }
 

@@ -26,7 +26,7 @@
 #define BN 128
 #define BK 64
 #define NTHREADS 256
-#define P8_MIN_TILES 96     // auto-selection threshold of the 8-wave 256 x 256 kernel (tiles of the launch)
+#define P8_MIN_TILES 96     // (experiments build) selection threshold of the 8-wave 256 x 256 kernel (tiles of the launch)
 
 struct GemmDev {
     const bf16_t* A; int64_t a_plane; int lda; const int* a_rows; int a_koff_group;
@@ -640,6 +640,173 @@ gemm_bf16_glds_kernel(const GemmDev p) {
 }
 
 
+// ---- routed experts, second product, ONE launch (vocal2music_moe.py:154-167: y = m_c FFN^c(u) + m_a FFN^a(u)) ------------------
+// The two w2 GEMMs (caption group: scatter m_c * H_c W2c^T as fp32; acoustic group: read it back, add m_a * H_a W2a^T, write bf16
+// planes) round-tripped a [N][768] fp32 partial sum through HBM: 37 MB written + 37 MB re-read per block evaluation at 8 clips, for
+// two launches at 10-13 % of the MFMA peak.  Here the tokens are bucketed by their (caption expert, acoustic expert) PAIR (E*E groups,
+// bucket_place_kernel) and ONE grouped launch walks K = 2H: first half A = the token's caption-slot row of the routed hidden tensor
+// against W2c[c], second half A = its acoustic-slot row against W2a[a] (two row gathers, one per K half).  The per-token gate weights
+// differ between the halves, so the first half's accumulator is parked in registers at the K midpoint and the epilogue forms
+// fmaf(m_a, acc_a, m_c * acc_c) - the same two roundings, in the same order, as the two-launch path: bit-identical (test).
+// Same tile / ring / swizzle as gemm_bf16_glds_kernel<*, 64, 2> (128 x 128 x 64, two workgroups per CU).
+struct PairDev {
+    const bf16_t* Hs; int ldh;                               // routed hidden [2N][H] bf16, slot order (caption slots, then acoustic slots)
+    const bf16_t* W2; int64_t w_stride; int ldw;             // [2E][D][H]
+    const int* pair_off; const int* pair_tok; const int2* pair_rows;
+    const float* mc; const float* ma;
+    bf16_t* out; int ldc;                                    // y planes [N][D] (one plane: bf16 production mode)
+    int N, D, H, E, n_tiles;
+};
+__global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) {
+    constexpr int BKT = 64, NST = 2, CH = 8, RS = 8, SPW = 4, LPT = 2 * SPW, OPB = BM * BKT * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * OPB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    int g = 0, row0 = 0, rows_end = 0, tile_n;
+    {
+        const int L = blockIdx.x, nN = p.n_tiles;
+        const int jx = L >> 3;
+        tile_n = jx % nN;
+        int tmg = (jx / nN) * 8 + (L & 7);
+        bool found = false;
+        const int G = p.E * p.E;
+        for (int gi = 0; gi < G; ++gi) {
+            const int lo = p.pair_off[gi], hi = p.pair_off[gi + 1];
+            const int nt = (hi - lo + BM - 1) / BM;
+            if (tmg < nt) { g = gi; row0 = lo + tmg * BM; rows_end = hi; found = true; break; }
+            tmg -= nt;
+        }
+        if (!found) return;
+    }
+    const int ec = g / p.E, ea = g - ec * p.E;
+    const int n0 = tile_n * BN;
+    const int KT = p.H / BKT;
+    const int total = 2 * KT;
+
+    const bf16_t* asrc[2][SPW]; const bf16_t* bsrc[2][SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+        const int s = wave * SPW + i;
+        const int r = RS * s + lane / CH;
+        const int cs = lane % CH;
+        const int c = cs ^ ((r >> 1) & 7);
+        int slot = row0 + r;
+        if (slot >= rows_end) slot = row0;
+        const int2 rows = p.pair_rows[slot];
+        asrc[0][i] = p.Hs + (int64_t)rows.x * p.ldh + c * 8;
+        asrc[1][i] = p.Hs + (int64_t)rows.y * p.ldh + c * 8;
+        int nrow = n0 + r;
+        if (nrow >= p.D) nrow = 0;
+        bsrc[0][i] = p.W2 + (int64_t)ec * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
+        bsrc[1][i] = p.W2 + (int64_t)(p.E + ea) * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
+    }
+    auto issue = [&](int t) {
+        const int st = t % NST;
+        const int half = t >= KT ? 1 : 0;
+        const int k0 = (t - half * KT) * BKT;
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int s = wave * SPW + i;
+            const bf16_t* ap = half ? asrc[1][i] : asrc[0][i];
+            const bf16_t* bp = half ? bsrc[1][i] : bsrc[0][i];
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ap + k0), (lds_ptr_t)(&lds[(st * 2 + 0) * OPB + s * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bp + k0), (lds_ptr_t)(&lds[(st * 2 + 1) * OPB + s * 1024]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2], accc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+
+    issue(0);
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < total; ++t) {
+        const int st = t % NST;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();           // tile t landed everywhere; everyone finished reading stage (t-1)%NST
+        if (t + 1 < total) issue(t + 1);
+        if (t == KT) {                          // K midpoint: park the caption product, start the acoustic one
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accc[i][j] = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                }
+        }
+        const unsigned char* As = &lds[(st * 2 + 0) * OPB];
+        const unsigned char* Bs = &lds[(st * 2 + 1) * OPB];
+        bf16x8 af[2][2], bf[2][2];
+        auto fload = [&](int ks, int slot) {
+            const int c = ks * 2 + fk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
+                bf[slot][i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
+            }
+        };
+        fload(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < BKT / 16) fload(ks + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue: a lane owns one token row and 4 consecutive columns per accumulator quad
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slot = row0 + wr * 64 + i * 32 + frow;
+            if (slot >= rows_end) continue;
+            const int tok = p.pair_tok[slot];
+            const float sc = p.mc[tok], sa = p.ma[tok];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
+                    if (n >= p.D) continue;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yc = sc * accc[i][j][q * 4 + e];          // what EPI_SCATTER_F32 stored
+                        o[e] = fmaf(sa, acc[i][j][q * 4 + e], yc);            // what EPI_SCATTER_ADD_PLANES added to it
+                    }
+                    store4p(p.out, 0, 1, (int64_t)tok * p.ldc + n, o);
+                }
+        }
+    }
+}
+int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st) {
+    if (a.H % 64 || a.D % 4 || a.E < 1 || a.E * a.E > 16) VB_FAIL(VB_E_INVALID, "moe_w2_pair: H=%d D=%d E=%d unsupported", a.H, a.D, a.E);
+    PairDev d;
+    d.Hs = a.Hs; d.ldh = a.H; d.W2 = a.W2; d.w_stride = (int64_t)a.D * a.H; d.ldw = a.H;
+    d.pair_off = a.pair_off; d.pair_tok = a.pair_tok; d.pair_rows = reinterpret_cast<const int2*>(a.pair_rows);
+    d.mc = a.mc; d.ma = a.ma; d.out = a.out; d.ldc = a.D; d.N = a.N; d.D = a.D; d.H = a.H; d.E = a.E;
+    d.n_tiles = cdiv(a.D, BN);
+    const int mt = cdiv(a.N, BM) + a.E * a.E;                    // upper bound of the row tiles over all pair groups
+    ProfScope prof(0, 2.0 * a.N * a.D * 2.0 * a.H, 2.0 * a.N * a.H * 2.0 + 2.0 * a.E * a.D * a.H * 2.0 + (double)a.N * a.D * 2.0, st);
+    hipLaunchKernelGGL(moe_w2_pair_kernel, dim3(d.n_tiles * ((mt + 7) / 8 * 8)), dim3(NTHREADS), 0, st, d);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // ---- variant 3: big block tiles, one workgroup per CU --------------------------------------------------------------
 // Per-block traces of the 128x128 kernel (tools/gemm_trace.py) show a k-iteration costs ~1500 cycles against 640 cycles
 // of MFMA: every iteration moves 32 KB through the CU's 64 B/clk vector-memory path (512 cycles at best) and waits for
@@ -833,6 +1000,9 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
     }
 }
 
+// ---- experiments (compiled only with -DVB_EXPERIMENTS: `VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build`; not part of the product
+// library): the 8-wave 256 x 256 kernel, measured slower inside the DiT, kept as the record of the experiment ----
+#ifdef VB_EXPERIMENTS
 // ---- variant 4: 256 x 256 tiles, 8 waves in two staggered groups ("ping-pong") ------------------------------------
 // What bounds the 4-wave kernels above is the L2 -> LDS feed (52-60 GB/s per CU whatever the ring, section 5 of DESIGN.md): at
 // 64 flop per byte DMA'd (128^2) or 96 (192^2) the MFMA pipe idles half the time, and with one wave per SIMD every barrier, DMA
@@ -1091,8 +1261,7 @@ static void launch_p8_v(const GemmDev& d, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NST * 2 * 256 * BKT * 2;
     static_assert(lds >= (size_t)256 * 68 * 4 && lds <= 160 * 1024, "LDS budget");
     static OnceFlags attr;
-    if (vb_first_use_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), (int)lds);
     hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), grid, dim3(512), lds, st, d);
 }
 #ifndef P8_DEFAULT_BKT
@@ -1123,9 +1292,12 @@ static void launch_p8(const GemmDev& d, dim3 grid, hipStream_t st, int variant) 
 template <int EPI> struct P8Epi { static constexpr bool ok = EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_QKV_ROPE || EPI == EPI_RESID_GATE ||
                                                             EPI == EPI_SWIGLU || EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES; };
 
+#endif  // VB_EXPERIMENTS
+
 template <int EPI, int TM, int TN, int NSTB>
 static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)NSTB * (64 * TM + 64 * TN) * 128;
+#ifdef VB_EXPERIMENTS
     if constexpr (EPI == EPI_F32 && TM == 3 && TN == 3) {
         const int abl = vb_tune().gemm_ablate;
         if (abl >= 1 && abl <= 3) {
@@ -1135,17 +1307,19 @@ static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
             return;
         }
     }
+#endif
     static_assert(lds >= (size_t)64 * (64 * TN + 4) * 4, "epilogue staging slab must fit in the ring");
     static OnceFlags attr;
-    if (vb_first_use_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), (int)lds);
     hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), grid, dim3(NTHREADS), lds, st, d);
 }
 
 template <int EPI>
 static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
-    // VB_GEMM_VARIANT (tuning knob): 0 register-staged, 1 DMA BK=64 x2 stages, 2 DMA BK=32 x4 stages, 3 DMA BK=32 x3 stages,
-    // 4 DMA BK=64 x3 stages.  Default 1 (fastest on the DiT shapes, tools/gemm_bench.py).
+    // 128 x 128 tiles, two workgroups per CU: tile DMA (global_load_lds) with BK = 64 x 2 stages; K % 64 = 32 (96-channel bands at 8
+    // experts) takes BK = 32 x 4 stages; anything else the register-staged kernel.  (tools/gemm_bench.py compared further ring shapes:
+    // VB_GEMM_VARIANT / VB_GEMM_ABLATE exist in the experiments build only.)
+#ifdef VB_EXPERIMENTS
     const int variant = vb_tune().gemm_variant;
     const int abl = vb_tune().gemm_ablate;
     if constexpr (EPI == EPI_F32) {
@@ -1155,11 +1329,13 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
         if (abl == 4 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 4>), grid, dim3(NTHREADS), 0, st, d); return; }
         if (abl == 5 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 5>), grid, dim3(NTHREADS), 0, st, d); return; }
     }
-    if (variant == 1 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2>), grid, dim3(NTHREADS), 0, st, d);
-    else if (variant == 1 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);   // K = 96 bands (8 experts)
-    else if (variant == 2 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);
-    else if (variant == 3 && d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d);
-    else if (variant == 4 && d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d);
+    if (variant == 0) { hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d); return; }
+    if (variant == 2 && d.K % 32 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d); return; }
+    if (variant == 3 && d.K % 32 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
+    if (variant == 4 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
+#endif
+    if (d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2>), grid, dim3(NTHREADS), 0, st, d);
+    else if (d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);   // K = 96 bands (8 experts)
     else hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
 }
 
@@ -1543,8 +1719,7 @@ int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
         const int nblk96 = cdiv(tiles96, 8 / a.E) * 8;
         constexpr size_t lds96 = (size_t)B96_BM * 128 + 8 * B96_SLOT;      // hidden chunk (32 KB) + 8 ring slots of 12 KB = 128 KB
         static OnceFlags attr96;
-        if (vb_first_use_on_device(attr96))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_ffn96_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds96);
+        vb_set_max_lds_once(attr96, reinterpret_cast<const void*>(band_ffn96_kernel), (int)lds96);
         ProfScope prof96(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H),
                          (double)a.M * a.E * a.band * (2.0 + 8.0) + (double)a.E * 3.0 * a.H * a.band * 2.0, st);
         hipLaunchKernelGGL(band_ffn96_kernel, dim3(nblk96), dim3(NTHREADS), lds96, st, d);
@@ -1556,8 +1731,7 @@ int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
     const int nblk = cdiv(row_tiles, per8) * 8;
     constexpr size_t lds = (size_t)BF_BM * 128 + 8 * 16384;   // hidden chunk (24 KB) + 8 ring slots of 16 KB = 152 KB
     static OnceFlags attr;
-    if (vb_first_use_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band_ffn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(band_ffn_kernel), (int)lds);
     ProfScope prof(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H),
                    (double)a.M * a.E * a.band * (2.0 + 8.0) + (double)a.E * 3.0 * a.H * a.band * 2.0, st);
     hipLaunchKernelGGL(band_ffn_kernel, dim3(nblk), dim3(NTHREADS), lds, st, d);
@@ -1618,6 +1792,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles) cfg = vb_tune().gemm_small;
         }
     }
+#ifdef VB_EXPERIMENTS
     // 8-wave 256 x 256 kernel (variant 4): taken when the problem makes enough of its tiles to occupy a good part of the chip - it
     // moves half the bytes per flop through the L2 -> LDS feed, so it wins even at ~55 % of the CUs busy (12032 x 768: 141 tiles);
     // small problems (one 20 s clip: 18 tiles) stay on the 128 x 128 kernel.  VB_GEMM_P8 = 0 off / 1..3 force a ring shape.
@@ -1638,6 +1813,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             else if (p8 < 0 && (vb_tune().gemm_p8_mask & (1 << a.epi)) && t88 >= P8_MIN_TILES) cfg = 88;     // per-epilogue opt-in (A/B tool)
         }
     }
+#endif
     const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
@@ -1647,9 +1823,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const int c = vb_tune().gemm_nchunk;
         if (c > 0 && d.n_tiles > c && d.n_tiles % c == 0) d.ncc = c;
     }
+#ifdef VB_EXPERIMENTS
+#define VB_P8_LAUNCH(E) if constexpr (P8Epi<E>::ok) launch_p8<E>(d, grid, st, vb_tune().gemm_p8);
+#else
+#define VB_P8_LAUNCH(E)
+#endif
 #define VB_GEMM_CASE(E) \
         case E: \
-            if (cfg == 88) { if constexpr (P8Epi<E>::ok) launch_p8<E>(d, grid, st, vb_tune().gemm_p8); } \
+            if (cfg == 88) { VB_P8_LAUNCH(E) } \
             else if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
             else if (cfg == 24) launch_big<E, 2, 4, 3>(d, grid, st); \
             else if (cfg == 42) launch_big<E, 4, 2, 3>(d, grid, st); \
@@ -1672,6 +1853,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         default: VB_FAIL(VB_E_INVALID, "gemm: bad epilogue %d", a.epi);
     }
 #undef VB_GEMM_CASE
+#undef VB_P8_LAUNCH
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

@@ -40,6 +40,15 @@ struct GemmArgs {
     int H = 1, hd = 1, Tpad = 0, D = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
+// routed experts, second product of BOTH groups in one launch over (caption, acoustic) pair buckets (bf16, E <= 4; moe_w2_pair_kernel):
+// out[tok][:] = m_c[tok] * (Hs[caption slot] W2[c]^T) + m_a[tok] * (Hs[acoustic slot] W2[E + a]^T), bit-identical to the two-launch path
+struct MoeW2PairArgs {
+    const bf16_t* Hs = nullptr; const bf16_t* W2 = nullptr;     // [2N][H] bf16 slot order; [2E][D][H]
+    const int* pair_off = nullptr; const int* pair_tok = nullptr; const int* pair_rows = nullptr;   // launch_bucket pair outputs
+    const float* mc = nullptr; const float* ma = nullptr; bf16_t* out = nullptr;                    // out [N][D] bf16
+    int N = 0, D = 0, H = 0, E = 0;
+};
+int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st);
 // fused band-expert FFN (bf16): out32[:, e*band .. ] += gate * ( W2_e . (silu(W1_e y_e) * (W3_e y_e)) ), y_e = y[:, e*band ..]
 struct BandFfnArgs {
     const bf16_t* y = nullptr; int ldy = 0;          // [M][ldy] bf16 (one plane)
@@ -173,7 +182,9 @@ struct ScoreRouterArgs {
 bool score_router_supported(int NS, int K, int E, int Hh);
 int launch_score_router(const ScoreRouterArgs& a, hipStream_t st);
 int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
-int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st);
+// (pair_off / pair_tok / pair_rows non-null, E <= 4: also bucket by (caption, acoustic) expert pair - see bucket_place_kernel)
+int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off = nullptr,
+                  int* pair_tok = nullptr, int* pair_rows = nullptr);
 int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this many ints
 int launch_gate_fold(Planes kc, Planes vct, const float* bq_s, const float* wcg, int Beff, int L, int Lpad, int Hh, int hd, int E,
                      float* cbias, float* vw, hipStream_t st);

@@ -104,8 +104,7 @@ static int launch_rowlin(const float* x, int x_ld, const int64_t* idx, const flo
     dim3 grid(cdiv(N, npb), row_groups);
     size_t sh = (size_t)RL_R * (K + 4) * sizeof(float);
     static OnceFlags attr_set[2];
-    if (vb_first_use_on_device(attr_set[MODE]))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowlin_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    vb_set_max_lds_once(attr_set[MODE], reinterpret_cast<const void*>(rowlin_kernel<MODE>), 160 * 1024 - 4096);
     hipLaunchKernelGGL(rowlin_kernel<MODE>, grid, dim3(256), sh, st, x, x_ld, idx, x2, x2_ld, x2_mod > 0 ? x2_mod : 1, shift, scale, mod_ld,
                        T > 0 ? T : 1, eps, W, bias, R, N, K, act_in, npb, out, out_ld, sin_rows);
     VB_CHECK_LAUNCH();

@@ -173,8 +173,7 @@ template <int NJ, int PP>
 static void launch_sr(const ScoreRouterDev& d, dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)SR_NST * (SR_BM + NJ * 128) * 64;
     static OnceFlags attr;
-    if (vb_first_use_on_device(attr))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(score_router_kernel<NJ, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(score_router_kernel<NJ, PP>), (int)lds);
     hipLaunchKernelGGL((score_router_kernel<NJ, PP>), grid, dim3(256), lds, st, d);
 }
 

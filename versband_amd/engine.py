@@ -64,7 +64,18 @@ class DiTEngine:
         self.np = 2 if precision == "split" else 1
         dev = ctx.device
         # engines of one process that serve different sub-batches share ONE packed copy of the weights (`share`)
-        self.packed = share.packed if share is not None and share.precision == precision else pack.pack_dit(state_dict, cfg, self.np, dev)
+        # (`share` must be an engine of the SAME configuration, precision and checkpoint: anything else would hand vb_dit_load another
+        #  model's pointer layout silently)
+        if share is not None:
+            if share.cfg != cfg or share.precision != precision:
+                raise ValueError(f"DiTEngine(share=...): the shared engine was built for {share.cfg} / {share.precision}, this one asks for {cfg} / {precision}")
+            if share._sd_id is not state_dict and share._sd_id is not None and state_dict is not None:
+                same = set(share._sd_id.keys()) == set(state_dict.keys()) and all(
+                    share._sd_id[k].data_ptr() == state_dict[k].data_ptr() for k in list(state_dict.keys())[:8])
+                if not same:
+                    raise ValueError("DiTEngine(share=...): the shared engine holds another checkpoint")
+        self._sd_id = state_dict
+        self.packed = share.packed if share is not None else pack.pack_dit(state_dict, cfg, self.np, dev)
         self.ccfg = L.DitConfig(cfg.in_channels, cfg.hidden_size, cfg.num_heads, cfg.depth, cfg.num_experts, cfg.ffn_hidden,
                                 cfg.context_dim, cfg.ori_dim, cfg.max_len, self.np, cfg.norm_eps)
         w = L.DitWeights()
@@ -78,7 +89,7 @@ class DiTEngine:
         L.check(ctx.lib.vb_dit_load(ctx.handle, C.byref(self.ccfg), C.byref(w)), "vb_dit_load")
         self._ws: Optional[Tensor] = None
         self._ws_key = None
-        self._checked: Dict[Tuple[int, int, int], bool] = {}     # (data_ptr, version, numel) of index tracks already range-checked
+        self._checked: Dict[tuple, tuple] = {}                   # range-checked resident index tracks: key -> (midi, beats, versions), references held
         self._tables: Dict[tuple, Tuple[Tensor, Tensor]] = {}    # device copies of the (t_idx, dt) step tables
         self._pcond: Dict[tuple, list] = {}                      # persistent conditioning buffers: key -> [buffer, generation]
         self._xbuf: Dict[tuple, Tensor] = {}                     # engine-owned sampler state (stable address for graph replay)
@@ -100,22 +111,32 @@ class DiTEngine:
         hipGraph.  A stale handle is refused loudly (generation check) instead of sampling from overwritten conditioning."""
         dev = self.ctx.device
         t5 = t5.to(dev, torch.float32).contiguous()
+        midi_in, beats_in = midi, beats
         midi = midi.to(dev, torch.int64).reshape(midi.shape[0], -1).contiguous()
         beats = beats.to(dev, torch.int64).reshape(beats.shape[0], -1).contiguous()
         B, T_mel = midi.shape
         Beff, Lc, _ = t5.shape
         nb = Beff // B
         assert nb * B == Beff and nb in (1, 2)
-        # range check of the embedding indices: ONE device->host read per new pair of tracks (identity + version), none when the
-        # same tensors come back (a serving loop / the benchmark re-submits resident inputs and must not sync the stream)
-        key = (midi.data_ptr(), midi._version, beats.data_ptr(), beats._version, midi.numel())
-        if key not in self._checked:
+        # range check of the embedding indices (embed_t_kernel reads table[idx * D ..] unclamped): ONE device->host read per new pair
+        # of tracks.  The check is skipped only when the CALLER's own tensors are what the kernel will read (resident int64 contiguous
+        # device tensors: .to() / reshape / contiguous returned views of the same storage) AND were checked before at the same
+        # version; the cache entry holds a reference to them, so their addresses cannot be recycled for other data while the entry
+        # lives.  Converted temporaries (CPU, int32, strided inputs) are checked on every call.
+        resident = (midi.data_ptr() == midi_in.data_ptr() and beats.data_ptr() == beats_in.data_ptr() and
+                    midi_in.dtype == torch.int64 and beats_in.dtype == torch.int64 and midi_in.device == midi.device and
+                    beats_in.device == beats.device and midi_in.is_contiguous() and beats_in.is_contiguous())
+        key = (midi.data_ptr(), beats.data_ptr(), midi.numel(), beats.numel())
+        hit = self._checked.get(key) if resident else None
+        # (a view of the same storage shares its version counter, and the held reference keeps that storage - hence the address - alive)
+        if hit is None or hit[2] != (midi_in._version, beats_in._version):
             lim = torch.stack([midi.min(), midi.max(), beats.min(), beats.max()]).tolist()
             if lim[0] < 0 or lim[1] >= 130 or lim[2] < 0 or lim[3] >= 3:
                 raise IndexError("midi/beats index out of range of the embedding tables (130 / 3 rows)")
-            if len(self._checked) > 64:
-                self._checked.clear()
-            self._checked[key] = True
+            if resident:
+                if len(self._checked) > 64:
+                    self._checked.clear()
+                self._checked[key] = (midi_in, beats_in, (midi_in._version, beats_in._version))
         n = self.ctx.lib.vb_dit_cond_bytes(C.byref(self.ccfg), B, nb, T, Lc)
         gen = None
         if persistent:
