@@ -596,11 +596,14 @@ def main():
         torch.cuda.synchronize()
     assert all(torch.isfinite(w["wav"]).all() for w in workers)
 
-    # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every launch of each class bracketed by
+    # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every 7th launch of each class bracketed by
     # HIP events on the launch stream.  This is the kernel-quality figure (roofline.frac): in the timed region below two
     # sub-batches share the CUs, so a launch's event-bracketed duration includes the other stream's kernels.
-    EVERY = 1            # every launch of the isolated pass is bracketed (a stride that divides the launches per network evaluation - 5
-                         # against 4 x 6 + 1 = 25 GEMM-class launches once the routed w2 became one launch - samples a biased subset)
+    EVERY = 7            # sampling stride: must be coprime with the launches per network evaluation (4 blocks x 6 + FinalLayer = 25 GEMM-class
+                         # launches since the routed w2 became one launch; 5 sampled the same five kernels for ever) and with the per-pass
+                         # counts of the other classes (200, 129, 18).  Bracketing EVERY launch is not an option: back-to-back event pairs
+                         # double the reading of the long conv kernels (60.8 ms against rocprofv3's 30), while a sampled launch between
+                         # un-bracketed neighbours agrees with rocprofv3 to 2 %.
     table, dominant = [], 0
     if not args.no_isolated:
         w = workers[0] if S == 1 else make_worker(B, rank * B, share=workers[0]["eng"])
@@ -758,7 +761,7 @@ def main():
             "device": {"name": torch.cuda.get_device_name(device), "clocks_during_timed_region": tele.summary(device)},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "how": ("dominant class = largest GPU time per pass; achieved = algorithmic flops of its event-timed launches / their "
-                                 "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every "
+                                 "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 7th "
                                  "launch bracketed by HIP events on the launch stream)") if iso else "timed-region launches (no isolated pass)",
                          "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
                          "traffic": traffic,

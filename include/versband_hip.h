@@ -274,6 +274,12 @@ int vb_router_top1(const float* logits, const float* gumbel, int N, int E, int32
  * first 2N entries are the slot -> token permutation and scratch = vb_route_bucket_scratch_ints(N, E) */
 int vb_route_bucket_scratch_ints(int N, int E);
 int vb_route_bucket(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, void* stream);
+/* the same bucketing ranked by (caption expert, acoustic expert) PAIR (E*E <= 16), what the single-launch routed w2 product reads
+ * (vocal2music_moe.py:154-167): pair_off int32[E*E+1] in caption-major order; the caption slots [0,N) ARE the pair slots, the acoustic
+ * slots [N,2N) hold the same buckets acoustic-major; pair_pa int32[N] = acoustic slot of the token in pair slot p.  Inside an expert
+ * group the rows are ordered by (other expert, token) instead of by token */
+int vb_route_bucket_pairs(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, int32_t* pair_off,
+                          int32_t* pair_pa, void* stream);
 /* generic GEMM  C[M][N] f32 = A[M][K] planes x B[N][K]^T planes (+bias) */
 int vb_gemm_bf16(const void* A, const void* Bw, const float* bias, int M, int N, int K, int np, float* C, void* stream);
 /* grouped SwiGLU expert FFN (FeedForward, flag_large_dit_moe.py:480-485) over routed buckets:

@@ -247,6 +247,35 @@ def test_route_bucket(lib, N, E):
         assert torch.equal(sel, want), f"group {g}: stable order violated"      # stable: tokens in ascending order
 
 
+@pytest.mark.parametrize("N,E", [(5000, 4), (12032, 4), (6016, 2), (777, 3)])
+def test_route_bucket_pairs(lib, N, E):
+    """pair mode: one rank per token by (caption, acoustic) expert pair; caption slots = pair slots (caption-major), acoustic slots =
+    the same buckets acoustic-major; group_off / perm stay a valid bucketing by expert, tokens ascending inside a PAIR bucket"""
+    ic = torch.from_numpy(prng.randint(13, N, 0, E)).int()
+    ia = torch.from_numpy(prng.randint(14, N, 0, E)).int()
+    ia[ic == 1] = 0                                    # empty pair buckets (1, a > 0)
+    off = torch.full((2 * E + 1,), -1, dtype=torch.int32, device="cuda")
+    poff = torch.full((E * E + 1,), -1, dtype=torch.int32, device="cuda")
+    perm = torch.full((2 * N + lib.vb_route_bucket_scratch_ints(N, E),), -1, dtype=torch.int32, device="cuda")
+    ppa = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.vb_route_bucket_pairs(L.ptr(dev(ic)), L.ptr(dev(ia)), N, E, L.ptr(off), L.ptr(perm), L.ptr(poff), L.ptr(ppa), L.stream_ptr()), "bucket")
+    sync()
+    off, poff, perm, ppa = off.cpu().long(), poff.cpu().long(), perm.cpu()[:2 * N].long(), ppa.cpu().long()
+    cnt = torch.cat([torch.bincount(ic.long(), minlength=E), torch.bincount(ia.long(), minlength=E)])
+    assert torch.equal(off, torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
+    pair = ic.long() * E + ia.long()
+    assert torch.equal(poff, torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(pair, minlength=E * E).cumsum(0)]))
+    for g in range(E * E):
+        assert torch.equal(perm[poff[g]:poff[g + 1]], (pair == g).nonzero().squeeze(1)), f"pair bucket {g}"
+    for g in range(2 * E):                             # every expert group holds exactly its tokens (any order)
+        src = ic if g < E else ia
+        assert torch.equal(perm[off[g]:off[g + 1]].sort().values, (src == (g % E)).nonzero().squeeze(1)), f"group {g}"
+    assert torch.equal(perm[ppa], perm[:N]) and int(ppa.min()) >= N and ppa.unique().numel() == N
+    # acoustic half: acoustic-major order of the same pair buckets
+    a_of_slot = ia.long()[perm[N:]]
+    assert bool((a_of_slot[1:] >= a_of_slot[:-1]).all())
+
+
 @pytest.mark.parametrize("npl", [1, 2])
 def test_grouped_swiglu(lib, npl):
     N, D, H, G = 700, 768, 512, 4

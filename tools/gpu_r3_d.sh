@@ -1,0 +1,29 @@
+#!/bin/bash
+# quick A/B: targeted tests + the one-stream bench line + per-kernel stats
+set -u
+TAG=${1:-r3d}
+TESTS=${2:-"tests/test_gpu_kernels.py tests/test_gpu_path.py"}
+mkdir -p gpurun_out/$TAG
+O=gpurun_out/$TAG
+export TMPDIR=/tmp
+timeout 1200 python -m pytest $TESTS -m gpu -q --tb=short -p no:cacheprovider -x > $O/gpu_tests.log 2>&1
+echo "gpu tests exit: $?" >> $O/gpu_tests.log
+tail -6 $O/gpu_tests.log
+timeout 300 python bench.py --no-cpu-baseline --no-pmc > $O/bench_c2.json 2> $O/bench_c2.err
+timeout 300 python bench.py --no-cpu-baseline --no-pmc --batch 1 --streams 1 --steps 4 --warmup 2 > $O/bench_b1.json 2> $O/bench_b1.err
+for f in c2 b1; do python - <<PY
+import json
+try:
+    d=json.loads([l for l in open('$O/bench_$f.json') if l.startswith('{')][-1])
+    print('$f', 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],2), 'frac', round(d['roofline']['frac'],4), 'parity', d['parity_check'] and d['parity_check']['ok'], d['device']['clocks_during_timed_region'].get('sclk_mhz_avg'))
+    for r in d['roofline']['classes']: print('   ', r['class'][:40], round(r['ms_per_pass'],2), 'ms', round(r['avg_launch_us'],1),'us', round(r['frac_of_mfma_peak'],4), r['launches_per_pass'])
+except Exception as e:
+    print('$f', 'FAILED', e)
+PY
+done
+R=$PWD; cd /tmp
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/s1 -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-isolated --no-pmc --no-parity-check --streams 1 > $R/$O/s1.log 2>&1
+cd $R
+f=$(find $O/s1 -name "*kernel_stats.csv" | head -1); cp "$f" $O/stream1_kernel_stats.csv
+python tools/prof_summary.py $O/stream1_kernel_stats.csv 3 22
+find $O/s1 -name "*kernel_trace.csv" -delete

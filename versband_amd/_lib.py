@@ -118,6 +118,7 @@ PROTOTYPES = {
     "vb_router_top1": (c_int, [P, P, c_int, c_int, P, P]),
     "vb_route_bucket_scratch_ints": (c_int, [c_int, c_int]),
     "vb_route_bucket": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_route_bucket_pairs": (c_int, [P, P, c_int, c_int, P, P, P, P, P]),
     "vb_gemm_bf16": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "vb_grouped_swiglu": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P, P]),
     "vb_attention": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

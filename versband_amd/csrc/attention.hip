@@ -13,9 +13,11 @@
 // V^T (stored d-major by the QKV GEMM epilogue) with two 8-byte LDS reads - no
 // cross-lane shuffle of P at all.
 // SPLIT = bf16x3 parity mode (hi*hi + lo*hi + hi*lo for both Q K^T and P V).
+// (Round 3, measured and dropped: the cross keys visited twice - statistics pass in front of the self pass, accumulate pass behind
+//  it - removes the 48-KB stash (LDS 74 -> 26 KB), but at two waves per SIMD the kernel runs 64.4 us against 61.7 with the stash, and
+//  three waves per SIMD need <= 168 registers where the kernel holds 254 (o 48 + s 32 + q 24 + K/V prefetch 24 + fragments): forced,
+//  the compiler spills 41.)
 #include <stdlib.h>
-
-#include <type_traits>
 
 #include "kernels.h"
 
@@ -43,6 +45,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
     constexpr int NP = SPLIT ? 2 : 1;
     __shared__ __attribute__((aligned(16))) bf16_t Kl[NP][KT * KPITCH];
     __shared__ __attribute__((aligned(16))) bf16_t Vl[NP][HD * VPITCH];
+    __shared__ float stash[4][48][64];     // the cross-attention result waits here while self-attention runs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 5, ql = lane & 31;
@@ -73,13 +76,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
-    // MODE 0: online softmax + P.V (self attention).  MODE 1: statistics only - running maximum and sum of the tile scores, no V
-    // traffic, no P.V.  MODE 2: P.V with a FIXED maximum m_io and every probability scaled by pscale (no running state): with
-    // (m, l) from a MODE-1 pass over the same keys, pscale = w / l adds the normalised, weighted result straight into acc.
-    auto kv_pass = [&](auto mode_c, const bf16_t* Kg, int64_t kplane, const bf16_t* Vg, int64_t vplane, int nkeys, int vpad, int kb_batch,
-                       f32x16 (&acc)[3], float& m_io, float& l_out, float pscale) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(mode_c)::value;
-        float m_run = MODE == 2 ? m_io : -1e30f, l_run = 0.f;
+    auto kv_pass = [&](const bf16_t* Kg, int64_t kplane, const bf16_t* Vg, int64_t vplane, int nkeys, int vpad, int kb_batch,
+                       f32x16 (&acc)[3], float& l_out) __attribute__((always_inline)) {
+        float m_run = -1e30f, l_run = 0.f;
         const int ntiles = (nkeys + KT - 1) / KT;
         // register prefetch (bf16 mode): the global loads of tile kt+1 are issued before tile kt is multiplied and
         // written to LDS after it, so their latency hides behind the MFMAs (split mode has no registers to spare)
@@ -93,11 +92,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 const bool ok = (key0 + key) < nkeys;
                 const bf16_t* src = Kg + ((int64_t)kb_batch * nkeys + (ok ? key0 + key : 0)) * p.D + h * HD + c * 8;
                 kr[i] = ok ? *reinterpret_cast<const uint4*>(src + pl * kplane) : make_uint4(0, 0, 0, 0);
-                if constexpr (MODE != 1) {
-                    const int d = id >> 3, c2 = id & 7;
-                    const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + d) * vpad + key0 + c2 * 8;
-                    vr[i] = *reinterpret_cast<const uint4*>(vs + pl * vplane);
-                }
+                const int d = id >> 3, c2 = id & 7;
+                const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + d) * vpad + key0 + c2 * 8;
+                vr[i] = *reinterpret_cast<const uint4*>(vs + pl * vplane);
             }
         };
         auto tile_store = [&](const uint4 (&kr)[3], const uint4 (&vr)[3], int pl) {
@@ -106,12 +103,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 const int id = tid + i * 256;
                 const int key = id / 12, c = id - key * 12;
                 *reinterpret_cast<uint4*>(&Kl[pl][key * KPITCH + c * 8]) = kr[i];
-                if constexpr (MODE != 1) {
-                    const int d = id >> 3, c2 = id & 7;
-                    uint2* dst = reinterpret_cast<uint2*>(&Vl[pl][d * VPITCH + c2 * 8]);
-                    dst[0] = make_uint2(vr[i].x, vr[i].y);
-                    dst[1] = make_uint2(vr[i].z, vr[i].w);
-                }
+                const int d = id >> 3, c2 = id & 7;
+                uint2* dst = reinterpret_cast<uint2*>(&Vl[pl][d * VPITCH + c2 * 8]);
+                dst[0] = make_uint2(vr[i].x, vr[i].y);
+                dst[1] = make_uint2(vr[i].z, vr[i].w);
             }
         };
         if constexpr (!SPLIT) tile_load(0, kreg, vreg, 0);
@@ -185,7 +180,6 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                         if (key >= nkeys) s[kb][r] = -INFINITY;
                     }
             }
-            if constexpr (MODE != 2) {
             float tmax = s[0][0];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -200,27 +194,22 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 m_run = m_new;
                 l_run *= alpha;
-                if constexpr (MODE == 0) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
-                }
-            }
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
             }
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -m_run));    // exp2(-inf) = 0 for masked keys
-                    if constexpr (MODE == 2) e *= pscale;
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -m_run));    // exp2(-inf) = 0 for masked keys
                     s[kb][r] = e;
                     psum += e;
                 }
             l_run += psum;
             }
-            if constexpr (MODE == 1) continue;
             // ---- O^T += V^T P^T   (k-slot e of lane group g <-> key base + 8*(e>>2) + 4g + (e&3))
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -253,28 +242,33 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 }
         }
         l_out = l_run + __shfl_xor(l_run, 32, 64);
-        m_io = m_run;
     };
 
-    // Two SEPARATE softmaxes share ONE accumulator set (48 registers) and no LDS parking: the cross keys (2 short tiles) are visited
-    // twice - a statistics pass (scores only: exact normaliser l_c and its maximum m_c) in front of the long self pass, and an
-    // accumulate pass behind it that adds w/l_c * exp2(s - m_c) V_y into the already normalised self result.  Costs 24 extra MFMAs
-    // per wave (+7 %) and drops the 48-KB stash: the workgroup's LDS goes from 74 KB to 26 KB (three workgroups per CU).
-    using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
-    const int kb_cross = p.kv_batch_mod > 0 ? (b % p.kv_batch_mod) : b;
-    float m_c = 0.f, l_c = 1.f, m_s = 0.f;
-    if (p.has_cross) kv_pass(M1{}, p.ky, p.ky_plane, p.vyt, p.vyt_plane, p.L, p.Lpad, kb_cross, o, m_c, l_c, 1.f);
+    // cross attention first (2 short tiles); its weighted, normalised result is parked in LDS so the long
+    // self-attention pass runs with a single accumulator set (keeps the kernel at 2 waves per SIMD)
+    if (p.has_cross) {
+        float lc;
+        const int kb_batch = p.kv_batch_mod > 0 ? (b % p.kv_batch_mod) : b;
+        kv_pass(p.ky, p.ky_plane, p.vyt, p.vyt_plane, p.L, p.Lpad, kb_batch, o, lc);
+        const float w = (p.cross_w ? p.cross_w[h] : 1.f) / lc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= w;
+    }
     if (p.has_self) {
-        kv_pass(M0{}, p.k, p.k_plane, p.vt, p.vt_plane, p.T, p.Tpad, b, o, m_s, res_l, 1.f);
+        if (p.has_cross) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { stash[wave][i * 16 + r][lane] = o[i][r]; o[i][r] = 0.f; }
+        }
+        kv_pass(p.k, p.k_plane, p.vt, p.vt_plane, p.T, p.Tpad, b, o, res_l);
         const float inv = 1.f / res_l;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= inv;
-    }
-    if (p.has_cross) {
-        float l_dummy;
-        kv_pass(M2{}, p.ky, p.ky_plane, p.vyt, p.vyt_plane, p.L, p.Lpad, kb_cross, o, m_c, l_dummy, (p.cross_w ? p.cross_w[h] : 1.f) / l_c);
+            for (int r = 0; r < 16; ++r) o[i][r] = o[i][r] * inv + (p.has_cross ? stash[wave][i * 16 + r][lane] : 0.f);
     }
     if (qrow < p.T) {
         const int64_t base = ((int64_t)b * p.T + qrow) * p.D + h * HD;

@@ -431,31 +431,36 @@ int launch_router_top1(const float* logits, const float* gumbel, int N, int E, i
 // `counts` lives right behind perm's 2N entries (perm buffers are sized 2N + nblk*2E + 64 by the engine).
 // ---------------------------------------------------------------------------
 #define BK_T 256
-#define BK_G 32          // groups a launch can rank: 2E expert groups (+ E*E (caption, acoustic) PAIR groups when E <= 4)
-// Pair mode (pair_off != null, E <= 4): the same launches also bucket the tokens by their (caption expert, acoustic expert) PAIR -
-// group 2E + c*E + a - for the single-launch w2 product (moe_w2_pair_kernel): pair_tok[p] = token of pair slot p, pair_rows[p] =
-// (caption slot, acoustic slot) of that token = the two rows of the routed hidden tensor the K-concatenated product gathers.
+#define BK_G 32          // groups a launch can rank: 2E expert groups, or E*E (caption, acoustic) PAIR groups when E*E <= 16
+// Pair mode (pair_off != null, E*E <= 16): the tokens are ranked ONCE, by their (caption expert c, acoustic expert a) pair.  Both
+// expert-group orders fall out of the same E*E counts: the caption slots are the pair slots in c-major order (a caption group = E
+// consecutive pair buckets), the acoustic slots the same buckets laid out a-major behind them - the order of the rows INSIDE an
+// expert group is free (every row of a grouped GEMM is independent), so one rank per token serves perm (both halves), group_off and
+// the single-launch w2 product (moe_w2_pair_kernel), whose caption-half rows are then simply its own row range:
+//   perm[p] = token of pair slot p = caption slot p;  perm[pair_pa[p]] = the same token's acoustic slot;  pair_off[E*E + 1].
+template <bool PAIRS>
 __global__ void __launch_bounds__(BK_T) bucket_count_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E, int G,
                                                            int* counts) {
     __shared__ int wc[4][BK_G];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x * BK_T + tid;
     const int gc = n < N ? ic[n] : -1, ga = n < N ? E + ia[n] : -1;
-    const int gp = n < N ? 2 * E + gc * E + (ga - E) : -1;
+    const int gp = n < N ? gc * E + (ga - E) : -1;
     for (int g = 0; g < G; ++g) {
-        const unsigned long long m = __ballot(g < E ? (gc == g) : (g < 2 * E ? (ga == g) : (gp == g)));
+        const unsigned long long m = __ballot(PAIRS ? (gp == g) : (g < E ? (gc == g) : (ga == g)));
         if (lane == 0) wc[wave][g] = __popcll(m);
     }
     __syncthreads();
     if (tid < G) counts[blockIdx.x * G + tid] = wc[0][tid] + wc[1][tid] + wc[2][tid] + wc[3][tid];
 }
+template <bool PAIRS>
 __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E, int G,
                                                            const int* __restrict__ counts, int nblk, int* group_off, int* perm,
-                                                           int* pair_off, int* pair_tok, int2* pair_rows) {
-    __shared__ int base[BK_G];        // slot of this block's first token of every group
+                                                           int* pair_off, int* pair_pa) {
+    __shared__ int base[BK_G];        // slot of this block's first token of every group (pair mode: caption slot)
+    __shared__ int base2[BK_G];       // pair mode: acoustic slot of this block's first token of every pair
     __shared__ int wc[4][BK_G];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G2 = 2 * E;
     // group start = sum of all earlier groups' totals; + this group's tokens in earlier blocks.  The counts table is
     // summed by the whole block (thread = (row-of-counts, group)), not by G serial threads.
     __shared__ int tot[BK_G], bef[BK_G];
@@ -473,57 +478,132 @@ __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restric
     }
     __syncthreads();
     if (tid < G) {
-        // expert groups count slots from 0 (caption groups, then acoustic groups: 2N slots); pair groups count pair slots from 0
         int before_groups = 0;
-        for (int g = (tid < G2 ? 0 : G2); g < tid; ++g) before_groups += tot[g];
+        for (int g = 0; g < tid; ++g) before_groups += tot[g];
         base[tid] = before_groups + bef[tid];
-        if (blockIdx.x == 0) {
-            if (tid < G2) {
-                group_off[tid] = before_groups;
-                if (tid == G2 - 1) group_off[G2] = before_groups + tot[tid];
-            } else {
-                pair_off[tid - G2] = before_groups;
-                if (tid == G - 1) pair_off[G - G2] = before_groups + tot[tid];
+        if constexpr (PAIRS) {
+            // a-major order of the same buckets: everything with a smaller acoustic expert, then the same a with a smaller caption expert
+            const int c = tid / E, a = tid - c * E;
+            int beforeT = 0;
+            for (int g = 0; g < G; ++g) {
+                const int c2 = g / E, a2 = g - c2 * E;
+                if (a2 < a || (a2 == a && c2 < c)) beforeT += tot[g];
             }
+            base2[tid] = N + beforeT + bef[tid];
+            if (blockIdx.x == 0) {
+                pair_off[tid] = before_groups;
+                if (tid == G - 1) pair_off[G] = before_groups + tot[tid];
+                if (a == 0) group_off[c] = before_groups;                 // caption group c starts at its first pair bucket
+                if (c == 0) group_off[E + a] = N + beforeT;               // acoustic group a starts at pair (0, a) in a-major order
+                if (tid == 0) { group_off[E] = N; group_off[2 * E] = 2 * N; }
+            }
+        } else if (blockIdx.x == 0) {
+            group_off[tid] = before_groups;
+            if (tid == G - 1) group_off[G] = before_groups + tot[tid];
         }
     }
     const int n = blockIdx.x * BK_T + tid;
     const int gc = n < N ? ic[n] : -1, ga = n < N ? E + ia[n] : -1;
-    const int gp = (n < N && G > G2) ? G2 + gc * E + (ga - E) : -1;
-    int rank_c = 0, rank_a = 0, rank_p = 0;
+    const int gp = n < N ? gc * E + (ga - E) : -1;
+    int rank_c = 0, rank_a = 0;
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int g = 0; g < G; ++g) {
-        const unsigned long long m = __ballot(g < E ? (gc == g) : (g < G2 ? (ga == g) : (gp == g)));
+        const unsigned long long m = __ballot(PAIRS ? (gp == g) : (g < E ? (gc == g) : (ga == g)));
         if (lane == 0) wc[wave][g] = __popcll(m);
-        if (g == gc) rank_c = __popcll(m & lower);
-        if (g == ga) rank_a = __popcll(m & lower);
-        if (g == gp) rank_p = __popcll(m & lower);
+        if constexpr (PAIRS) {
+            if (g == gp) rank_c = __popcll(m & lower);
+        } else {
+            if (g == gc) rank_c = __popcll(m & lower);
+            if (g == ga) rank_a = __popcll(m & lower);
+        }
     }
     __syncthreads();
     if (n < N) {
-        int pc = base[gc] + rank_c, pa = base[ga] + rank_a;
-        for (int w = 0; w < wave; ++w) { pc += wc[w][gc]; pa += wc[w][ga]; }
-        perm[pc] = n;
-        perm[pa] = n;
-        if (gp >= 0) {
-            int pp = base[gp] + rank_p;
-            for (int w = 0; w < wave; ++w) pp += wc[w][gp];
-            pair_tok[pp] = n;
-            pair_rows[pp] = make_int2(pc, pa);
+        if constexpr (PAIRS) {
+            int r = rank_c;
+            for (int w = 0; w < wave; ++w) r += wc[w][gp];
+            const int pc = base[gp] + r, pa = base2[gp] + r;
+            perm[pc] = n;
+            perm[pa] = n;
+            pair_pa[pc] = pa;
+        } else {
+            int pc = base[gc] + rank_c, pa = base[ga] + rank_a;
+            for (int w = 0; w < wave; ++w) { pc += wc[w][gc]; pa += wc[w][ga]; }
+            perm[pc] = n;
+            perm[pa] = n;
         }
     }
 }
-int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off, int* pair_tok,
-                  int* pair_rows) {
+// Small token counts (one or two clips: the reference's serving shape, scripts/test_final.py:357): count + place in ONE launch of one
+// 1024-thread workgroup - at 1504 tokens the two multi-block kernels above are two ~4.6-us launch floors for 6 blocks of work.
+// Same result, bit for bit (stable: ascending token order inside a group).
+#define BKS_T 1024
+#define BKS_CH 4            // chunks of 1024 tokens: N <= 4096
+__global__ void __launch_bounds__(BKS_T) bucket_small_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
+                                                            int* group_off, int* perm) {
+    __shared__ int cnt[BKS_CH * 16][BK_G];      // [chunk * 16 + wave][group]: count, then exclusive prefix inside the group
+    __shared__ int gbase[BK_G + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = 2 * E;
+    const int nch = (N + BKS_T - 1) / BKS_T;
+    int gc[BKS_CH], ga[BKS_CH], rc[BKS_CH], ra[BKS_CH];
+    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int ch = 0; ch < BKS_CH; ++ch) {
+        gc[ch] = -1; ga[ch] = -1; rc[ch] = 0; ra[ch] = 0;
+        if (ch < nch) {
+            const int n = ch * BKS_T + tid;
+            if (n < N) { gc[ch] = ic[n]; ga[ch] = E + ia[n]; }
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long m = __ballot(g < E ? (gc[ch] == g) : (ga[ch] == g));
+                if (lane == 0) cnt[ch * 16 + wave][g] = __popcll(m);
+                if (g == gc[ch]) rc[ch] = __popcll(m & lower);
+                if (g == ga[ch]) ra[ch] = __popcll(m & lower);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
+        int run = 0;
+        for (int i = 0; i < nch * 16; ++i) { const int c = cnt[i][tid]; cnt[i][tid] = run; run += c; }
+        gbase[tid + 1] = run;          // group total for now
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int g = 0; g < G; ++g) { const int t = gbase[g + 1]; gbase[g] = run; run += t; }
+        gbase[G] = run;
+    }
+    __syncthreads();
+    if (tid <= G) group_off[tid] = gbase[tid];
+#pragma unroll
+    for (int ch = 0; ch < BKS_CH; ++ch) {
+        const int n = ch * BKS_T + tid;
+        if (ch < nch && n < N) {
+            perm[gbase[gc[ch]] + cnt[ch * 16 + wave][gc[ch]] + rc[ch]] = n;
+            perm[gbase[ga[ch]] + cnt[ch * 16 + wave][ga[ch]] + ra[ch]] = n;
+        }
+    }
+}
+int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off, int* pair_pa) {
     if (E > 16) VB_FAIL(VB_E_INVALID, "bucket: E=%d > 16", E);
     const bool pairs = pair_off != nullptr;
-    const int G = 2 * E + (pairs ? E * E : 0);
-    if (G > BK_G) VB_FAIL(VB_E_INVALID, "bucket: %d groups > %d (pair mode needs E <= 4)", G, BK_G);
+    if (!pairs && N <= BKS_T * BKS_CH) {
+        hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(BKS_T), 0, st, ic, ia, N, E, group_off, perm);
+        VB_CHECK_LAUNCH();
+        return VB_OK;
+    }
+    if (pairs && E * E > 16) VB_FAIL(VB_E_INVALID, "bucket: pair mode needs E*E <= 16 (E=%d)", E);
+    const int G = pairs ? E * E : 2 * E;
     const int nblk = cdiv(N, BK_T);
     int* counts = perm + 2 * (size_t)N;          // scratch tail of the perm buffer (see bucket_scratch_ints)
-    hipLaunchKernelGGL(bucket_count_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
-    hipLaunchKernelGGL(bucket_place_kernel, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts, nblk, group_off, perm, pair_off, pair_tok,
-                       reinterpret_cast<int2*>(pair_rows));
+    if (pairs) {
+        hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
+        hipLaunchKernelGGL(bucket_place_kernel<true>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts, nblk, group_off, perm, pair_off, pair_pa);
+    } else {
+        hipLaunchKernelGGL(bucket_count_kernel<false>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
+        hipLaunchKernelGGL(bucket_place_kernel<false>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts, nblk, group_off, perm, nullptr, nullptr);
+    }
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

@@ -224,7 +224,7 @@ struct WsL {
     bf16_t* modA;                                                   // A operand (planes) of the adaLN tabulation GEMM
     float *temb0_s, *temb_s, *hl_s, *mod_s; int64_t* row_step;     // per-sample tables of the conditioning vectors of every step
     bf16_t *u, *q, *k, *vt, *a, *qm, *cqa, *Hs, *y, *Hf;
-    int *ic, *ia, *group_off, *perm, *pair_off, *pair_tok, *pair_rows;
+    int *ic, *ia, *group_off, *perm, *pair_off, *pair_pa;
     // precompute temporaries
     float *tA, *tB, *tC, *tD, *tE, *cap_pre, *cap32, *pooled, *pooled_ln;
     bf16_t *t5p, *gel, *capp, *yp;
@@ -270,8 +270,7 @@ static WsL carve_ws(void* base, const vb_dit_config& c, int B, int nb, int T, in
     o.group_off = cv.take<int>(2 * E + 1);
     o.perm = cv.take<int>(2 * N + bucket_scratch_ints((int)N, E));
     o.pair_off = cv.take<int>(32);
-    o.pair_tok = cv.take<int>(N);
-    o.pair_rows = cv.take<int>(2 * N);
+    o.pair_pa = cv.take<int>(N);
     // precompute temporaries
     const int T_mel = 2 * T + 8;
     o.tA = cv.take<float>((size_t)B * D * T_mel);
@@ -520,7 +519,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         // routed w2 as ONE launch over (caption, acoustic) pair buckets: bf16 mode, E*E <= 16 groups, and enough tokens that the
         // pair tiles' padding (<= one 128-row tile per pair) stays small; otherwise the two grouped w2 launches (bit-identical)
         const bool w2_pair = np == 1 && E * E <= 16 && H % 64 == 0 && vb_tune().w2_pair && N >= 256 * E * E;
-        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st, w2_pair ? s.pair_off : nullptr, s.pair_tok, s.pair_rows));
+        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st, w2_pair ? s.pair_off : nullptr, s.pair_pa));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 1) * N, s.ia, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -533,7 +532,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         VB_TRY(launch_gemm(g, st));
         if (w2_pair) {
             MoeW2PairArgs pw;
-            pw.Hs = Hs.p; pw.W2 = (const bf16_t*)bw.w2; pw.pair_off = s.pair_off; pw.pair_tok = s.pair_tok; pw.pair_rows = s.pair_rows;
+            pw.Hs = Hs.p; pw.W2 = (const bf16_t*)bw.w2; pw.pair_off = s.pair_off; pw.perm = s.perm; pw.pair_pa = s.pair_pa;
             pw.mc = s.mc; pw.ma = s.ma; pw.out = y.p; pw.N = N; pw.D = D; pw.H = H; pw.E = E;
             VB_TRY(launch_moe_w2_pair(pw, st));
         } else {
@@ -1084,6 +1083,11 @@ int vb_router_top1(const float* logits, const float* gumbel, int N, int E, int32
     return launch_router_top1(logits, gumbel, N, E, idx, (hipStream_t)stream);
 }
 int vb_route_bucket_scratch_ints(int N, int E) { return bucket_scratch_ints(N, E); }
+int vb_route_bucket_pairs(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, int32_t* pair_off,
+                          int32_t* pair_pa, void* stream) {
+    if (!pair_off || !pair_pa) VB_FAIL(VB_E_INVALID, "route_bucket_pairs: null pair outputs");
+    return launch_bucket(ic, ia, N, E, group_off, perm, (hipStream_t)stream, pair_off, pair_pa);
+}
 int vb_route_bucket(const int32_t* ic, const int32_t* ia, int N, int E, int32_t* group_off, int32_t* perm, void* stream) {
     return launch_bucket(ic, ia, N, E, group_off, perm, (hipStream_t)stream);
 }

@@ -644,15 +644,16 @@ gemm_bf16_glds_kernel(const GemmDev p) {
 // The two w2 GEMMs (caption group: scatter m_c * H_c W2c^T as fp32; acoustic group: read it back, add m_a * H_a W2a^T, write bf16
 // planes) round-tripped a [N][768] fp32 partial sum through HBM: 37 MB written + 37 MB re-read per block evaluation at 8 clips, for
 // two launches at 10-13 % of the MFMA peak.  Here the tokens are bucketed by their (caption expert, acoustic expert) PAIR (E*E groups,
-// bucket_place_kernel) and ONE grouped launch walks K = 2H: first half A = the token's caption-slot row of the routed hidden tensor
-// against W2c[c], second half A = its acoustic-slot row against W2a[a] (two row gathers, one per K half).  The per-token gate weights
+// bucket_place_kernel: the caption slots ARE the pair slots) and ONE grouped launch walks K = 2H: first half A = the tile's own rows of
+// the routed hidden tensor (caption slots, contiguous) against W2c[c], second half A = the tokens' acoustic-slot rows (gathered)
+// against W2a[a].  The per-token gate weights
 // differ between the halves, so the first half's accumulator is parked in registers at the K midpoint and the epilogue forms
 // fmaf(m_a, acc_a, m_c * acc_c) - the same two roundings, in the same order, as the two-launch path: bit-identical (test).
 // Same tile / ring / swizzle as gemm_bf16_glds_kernel<*, 64, 2> (128 x 128 x 64, two workgroups per CU).
 struct PairDev {
     const bf16_t* Hs; int ldh;                               // routed hidden [2N][H] bf16, slot order (caption slots, then acoustic slots)
     const bf16_t* W2; int64_t w_stride; int ldw;             // [2E][D][H]
-    const int* pair_off; const int* pair_tok; const int2* pair_rows;
+    const int* pair_off; const int* perm; const int* pair_pa;   // pair slot p: caption row = p, acoustic row = pair_pa[p], token = perm[p]
     const float* mc; const float* ma;
     bf16_t* out; int ldc;                                    // y planes [N][D] (one plane: bf16 production mode)
     int N, D, H, E, n_tiles;
@@ -695,9 +696,8 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
         const int c = cs ^ ((r >> 1) & 7);
         int slot = row0 + r;
         if (slot >= rows_end) slot = row0;
-        const int2 rows = p.pair_rows[slot];
-        asrc[0][i] = p.Hs + (int64_t)rows.x * p.ldh + c * 8;
-        asrc[1][i] = p.Hs + (int64_t)rows.y * p.ldh + c * 8;
+        asrc[0][i] = p.Hs + (int64_t)slot * p.ldh + c * 8;                    // caption half: the pair slots ARE the caption slots
+        asrc[1][i] = p.Hs + (int64_t)p.pair_pa[slot] * p.ldh + c * 8;         // acoustic half: gathered
         int nrow = n0 + r;
         if (nrow >= p.D) nrow = 0;
         bsrc[0][i] = p.W2 + (int64_t)ec * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
         for (int i = 0; i < 2; ++i) {
             const int slot = row0 + wr * 64 + i * 32 + frow;
             if (slot >= rows_end) continue;
-            const int tok = p.pair_tok[slot];
+            const int tok = p.perm[slot];
             const float sc = p.mc[tok], sa = p.ma[tok];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -797,7 +797,7 @@ int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st) {
     if (a.H % 64 || a.D % 4 || a.E < 1 || a.E * a.E > 16) VB_FAIL(VB_E_INVALID, "moe_w2_pair: H=%d D=%d E=%d unsupported", a.H, a.D, a.E);
     PairDev d;
     d.Hs = a.Hs; d.ldh = a.H; d.W2 = a.W2; d.w_stride = (int64_t)a.D * a.H; d.ldw = a.H;
-    d.pair_off = a.pair_off; d.pair_tok = a.pair_tok; d.pair_rows = reinterpret_cast<const int2*>(a.pair_rows);
+    d.pair_off = a.pair_off; d.perm = a.perm; d.pair_pa = a.pair_pa;
     d.mc = a.mc; d.ma = a.ma; d.out = a.out; d.ldc = a.D; d.N = a.N; d.D = a.D; d.H = a.H; d.E = a.E;
     d.n_tiles = cdiv(a.D, BN);
     const int mt = cdiv(a.N, BM) + a.E * a.E;                    // upper bound of the row tiles over all pair groups

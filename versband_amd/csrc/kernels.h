@@ -44,7 +44,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st);
 // out[tok][:] = m_c[tok] * (Hs[caption slot] W2[c]^T) + m_a[tok] * (Hs[acoustic slot] W2[E + a]^T), bit-identical to the two-launch path
 struct MoeW2PairArgs {
     const bf16_t* Hs = nullptr; const bf16_t* W2 = nullptr;     // [2N][H] bf16 slot order; [2E][D][H]
-    const int* pair_off = nullptr; const int* pair_tok = nullptr; const int* pair_rows = nullptr;   // launch_bucket pair outputs
+    const int* pair_off = nullptr; const int* perm = nullptr; const int* pair_pa = nullptr;        // launch_bucket pair-mode outputs
     const float* mc = nullptr; const float* ma = nullptr; bf16_t* out = nullptr;                    // out [N][D] bf16
     int N = 0, D = 0, H = 0, E = 0;
 };
@@ -182,9 +182,10 @@ struct ScoreRouterArgs {
 bool score_router_supported(int NS, int K, int E, int Hh);
 int launch_score_router(const ScoreRouterArgs& a, hipStream_t st);
 int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
-// (pair_off / pair_tok / pair_rows non-null, E <= 4: also bucket by (caption, acoustic) expert pair - see bucket_place_kernel)
+// (pair_off / pair_pa non-null, E*E <= 16: rank by (caption, acoustic) expert PAIR; both expert-group orders derive from it - see
+//  bucket_place_kernel.  pair_off [E*E + 1], pair_pa [N] = acoustic slot of the token in pair / caption slot p)
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off = nullptr,
-                  int* pair_tok = nullptr, int* pair_rows = nullptr);
+                  int* pair_pa = nullptr);
 int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this many ints
 int launch_gate_fold(Planes kc, Planes vct, const float* bq_s, const float* wcg, int Beff, int L, int Lpad, int Hh, int hd, int E,
                      float* cbias, float* vw, hipStream_t st);
