@@ -391,6 +391,29 @@ def test_single_launch_routed_w2_matches_two_launch_path(engines, monkeypatch, B
     assert torch.equal(v1, v2), describe("single-launch pair w2 vs two launches", v1, v2)
 
 
+@pytest.mark.parametrize("prec,B,T", [("bf16", 4, 752), ("split", 3, 700)])
+def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T):
+    """The QKV + RoPE GEMM fills its weight tile with permuted source rows so a lane's accumulator holds 16 CONSECUTIVE output columns
+    (16-byte q / k stores and RoPE-table loads instead of 8-byte ones): the same values in other lanes - the DiT output must not change
+    by a bit against the quad layout (VB_QKV_P16_OFF=1), in both precisions, full and ragged row tiles."""
+    eng = engines[(4, prec)]
+    Lc = 80
+    inp = clip_batch(B, T, Lc)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2 * B,), 123, dtype=torch.int64)
+    v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
+    torch.cuda.synchronize()
+    v1, r1 = v1.clone(), r1.clone()
+    monkeypatch.setenv("VB_QKV_P16_OFF", "1")
+    L.load().vb_tune_reload()
+    v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("VB_QKV_P16_OFF")
+    L.load().vb_tune_reload()
+    assert torch.isfinite(v1).all() and torch.equal(r1, r2)
+    assert torch.equal(v1, v2), describe("P16 vs quad column layout of the QKV epilogue", v1, v2)
+
+
 @needs_experiments
 @pytest.mark.parametrize("E,B,T", [(4, 4, 752), (4, 6, 500), (8, 4, 752)])
 def test_fused_score_router_matches_two_launches(ctx, sds, engines, monkeypatch, E, B, T):

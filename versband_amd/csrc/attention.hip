@@ -26,6 +26,9 @@
 #define KPITCH 104            // bf16 elements per K row in LDS (208 B: 13 x 16 B -> conflict-free b128 reads)
 #define VPITCH 68             // bf16 elements per V^T row in LDS (136 B -> conflict-free b64 reads)
 
+// source row of LDS row r of a 32-row MFMA operand tile in the "16 consecutive columns per lane" layout (see gemm_bf16.hip: P16)
+__device__ __forceinline__ int p16_row(int r) { const int c = r & 31; return (r & ~31) + ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3); }
+
 struct AttnDev {
     const bf16_t* q; int64_t q_plane;
     const bf16_t* k; int64_t k_plane;
@@ -93,7 +96,9 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
                 const bf16_t* src = Kg + ((int64_t)kb_batch * nkeys + (ok ? key0 + key : 0)) * p.D + h * HD + c * 8;
                 kr[i] = ok ? *reinterpret_cast<const uint4*>(src + pl * kplane) : make_uint4(0, 0, 0, 0);
                 const int d = id >> 3, c2 = id & 7;
-                const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + d) * vpad + key0 + c2 * 8;
+                // (LDS row d of the V^T tile holds V^T row pi(d): the O accumulator then carries 16 CONSECUTIVE head-dim columns per
+                //  lane and the result leaves as 16-byte stores - see the epilogue)
+                const bf16_t* vs = Vg + ((int64_t)(kb_batch * p.H + h) * HD + p16_row(d)) * vpad + key0 + c2 * 8;
                 vr[i] = *reinterpret_cast<const uint4*>(vs + pl * vplane);
             }
         };
@@ -275,17 +280,17 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnDev p) {
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int d0 = dt * 32 + 8 * rg + 4 * g;
-                bf16x4 hi;
+            for (int hf = 0; hf < 2; ++hf) {
+                const int d0 = dt * 32 + 16 * g + 8 * hf;           // accumulator register r <-> head-dim column dt*32 + 16 g + r
+                bf16x8 hi;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hi[i] = f2bf(o[dt][rg * 4 + i]);
-                *reinterpret_cast<bf16x4*>(p.out + base + d0) = hi;
+                for (int i = 0; i < 8; ++i) hi[i] = f2bf(o[dt][hf * 8 + i]);
+                *reinterpret_cast<bf16x8*>(p.out + base + d0) = hi;
                 if (p.out_np == 2) {
-                    bf16x4 lo;
+                    bf16x8 lo;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) lo[i] = f2bf(o[dt][rg * 4 + i] - bf2f(hi[i]));
-                    *reinterpret_cast<bf16x4*>(p.out + p.out_plane + base + d0) = lo;
+                    for (int i = 0; i < 8; ++i) lo[i] = f2bf(o[dt][hf * 8 + i] - bf2f(hi[i]));
+                    *reinterpret_cast<bf16x8*>(p.out + p.out_plane + base + d0) = lo;
                 }
             }
     }

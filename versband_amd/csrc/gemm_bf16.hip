@@ -67,6 +67,30 @@ __device__ __forceinline__ void store1p(bf16_t* base, int64_t plane, int np, int
     if (np == 2) base[plane + idx] = f2bf(v - bf2f(hi));
 }
 
+// "P16" column layout: the MFMA accumulator of a 32 x 32 tile gives lane (row, fk) the columns q*8 + fk*4 + e (four separate quads).  When
+// LDS row c' of the weight tile is filled with weight row pi(c') = ((c'>>2)&1)*16 + (c'>>3)*4 + (c'&3) instead of c' (a permutation of
+// the SOURCE rows of the tile DMA: nothing else moves, the fragment reads stay conflict-free), the same accumulator holds the 16
+// CONSECUTIVE output columns fk*16 .. fk*16+15 of the lane's row: bf16 results leave as 16-byte stores (two per tile instead of four
+// 8-byte ones), RoPE table entries arrive as 16-byte loads, and every row gets 64 contiguous bytes per tile.  Same values, same
+// arithmetic - only which lane holds what.
+__device__ __forceinline__ int p16_src_row(int r) { const int c = r & 31; return (r & ~31) + ((c >> 2) & 1) * 16 + (c >> 3) * 4 + (c & 3); }
+__device__ __forceinline__ void store8p(bf16_t* base, int64_t plane, int np, int64_t idx, const float v[8]) {
+    bf16x8 hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = f2bf(v[i]);
+    *reinterpret_cast<bf16x8*>(base + idx) = hi;
+    if (np == 2) {
+        bf16x8 lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lo[i] = f2bf(v[i] - bf2f(hi[i]));
+        *reinterpret_cast<bf16x8*>(base + plane + idx) = lo;
+    }
+}
+// QKV + RoPE epilogue of one wave in the P16 layout (same arithmetic as epi_store<EPI_QKV_ROPE>, element for element)
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_qkv_p16(const struct GemmDev& p, f32x16 (&acc)[TM][TN], int row_base, int rows_end, int n_base,
+                                                      int frow, int fk);
+
 // Epilogue in two halves.  epi_load<EPI>() issues every global LOAD an output quad needs (bias, residual + gate,
 // RoPE table entries, partial expert sum); epi_store<EPI>() does the math and the stores.  The kernels call epi_load
 // for all quads of a 32-row slab first and only then epi_store: vmcnt retires loads and stores in order, so a load
@@ -216,6 +240,81 @@ __device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&
                 float v[4] = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
                 epi_store<EPI>(p, g, slot, tok, scale, n, v, pre[j][q]);
             }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_qkv_p16(const GemmDev& p, f32x16 (&acc)[TM][TN], int row_base, int rows_end, int n_base,
+                                                      int frow, int fk) {
+#pragma clang fp contract(off)
+    const int hd2 = p.hd >> 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = row_base + i * 32 + frow;
+        if (m >= rows_end) continue;
+        const int b = fdiv(m, p.rT), t = m - b * p.T;
+        // loads of the slab first (RoPE table: 8 pairs = two 16-byte loads each for cos and sin), then math + stores
+        float4 cs[TN][2], sn[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32 + fk * 16;
+            if (n < 2 * p.D) {
+                const int nn = n - fdiv(n, p.rD) * p.D;
+                const int jd = (nn - fdiv(nn, p.rhd) * p.hd) >> 1;
+                const float* cp = p.rope_cos + (int64_t)t * hd2 + jd;
+                const float* sp = p.rope_sin + (int64_t)t * hd2 + jd;
+                cs[j][0] = *reinterpret_cast<const float4*>(cp); cs[j][1] = *reinterpret_cast<const float4*>(cp + 4);
+                sn[j][0] = *reinterpret_cast<const float4*>(sp); sn[j][1] = *reinterpret_cast<const float4*>(sp + 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32 + fk * 16;
+            if (n >= p.N) continue;                          // N % 16 == 0 is required on this path
+            const int sec = fdiv(n, p.rD);
+            const int nn = n - sec * p.D;
+            if (sec < 2) {
+                const float c8[8] = {cs[j][0].x, cs[j][0].y, cs[j][0].z, cs[j][0].w, cs[j][1].x, cs[j][1].y, cs[j][1].z, cs[j][1].w};
+                const float s8[8] = {sn[j][0].x, sn[j][0].y, sn[j][0].z, sn[j][0].w, sn[j][1].x, sn[j][1].y, sn[j][1].z, sn[j][1].w};
+                float o[16];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v0 = acc[i][j][2 * e], v1 = acc[i][j][2 * e + 1];
+                    o[2 * e] = fmaf(v0, c8[e], -(v1 * s8[e]));
+                    o[2 * e + 1] = fmaf(v0, s8[e], v1 * c8[e]);
+                }
+                bf16_t* dst = sec == 0 ? p.q : p.k;
+                const int64_t pl = sec == 0 ? p.q_plane : p.k_plane;
+                store8p(dst, pl, p.qkv_np, (int64_t)m * p.D + nn, o);
+                store8p(dst, pl, p.qkv_np, (int64_t)m * p.D + nn + 8, o + 8);
+            } else {
+                const int h = fdiv(nn, p.rhd), d0 = nn - h * p.hd;          // 16 | hd: the 16 columns stay inside one head
+                const int64_t base = ((int64_t)(b * p.H + h) * p.hd + d0) * p.Tpad + t;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) store1p(p.vt, p.vt_plane, p.qkv_np, base + (int64_t)e * p.Tpad, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+// SwiGLU epilogue of one wave in the P16 layout: 16 consecutive (w1, w3)-interleaved columns = 8 hidden values = one 16-byte store
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_swiglu_p16(const GemmDev& p, int g, f32x16 (&acc)[TM][TN], int row_base, int rows_end, int n_base,
+                                                         int frow, int fk) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = row_base + i * 32 + frow;
+        if (m >= rows_end) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32 + fk * 16;
+            if (n >= p.N) continue;                          // N % 16 == 0 is required on this path
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = silu_f(acc[i][j][2 * e]) * acc[i][j][2 * e + 1];
+            store8p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + (n >> 1), o);
+        }
     }
 }
 
@@ -472,9 +571,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #define STAGED_EPI(E) (((VB_STAGED_MASK) >> (E)) & 1)
 
 // ABL (tuning only): 1 = no tile DMA in the loop, 2 = no MFMA, 3 = no LDS fragment reads
-template <int EPI, int BKT, int NST, int ABL = 0>
+template <int EPI, int BKT, int NST, int ABL = 0, bool P16 = false>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(BKT * NST == 96 ? 3 : 1, BKT * NST == 96 ? 3 : 8)))
 gemm_bf16_glds_kernel(const GemmDev p) {
+    static_assert(!P16 || EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU, "the P16 column layout is wired for the QKV + RoPE and SwiGLU epilogues");
     constexpr int CH = BKT / 8;              // 16-B chunks per tile row
     constexpr int RS = 64 / CH;              // tile rows covered by one wave-wide DMA (1 KB)
     constexpr int SPW = CH / 2;              // DMA pieces per wave per operand per tile
@@ -536,7 +636,7 @@ gemm_bf16_glds_kernel(const GemmDev p) {
         if (slot >= rows_end) slot = row0;
         const int arow = p.a_rows ? p.a_rows[slot] : slot;
         asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
-        int nrow = n0 + r;
+        int nrow = n0 + (P16 ? p16_src_row(r) : r);
         if (nrow >= p.N) nrow = 0;
         bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
     }
@@ -624,7 +724,9 @@ gemm_bf16_glds_kernel(const GemmDev p) {
             for (int j = 0; j < 2; ++j) sink += acc[i][j][0] + acc[i][j][9];
         if (sink == 12345.678f) p.out32[0] = sink;
     } else {
-        if constexpr (STAGED_EPI(EPI)) staged_epilogue<EPI, 2, 2>(p, g, acc, reinterpret_cast<float*>(lds), row0, rows_end, n0, tid, wr, wc, frow, fk);
+        if constexpr (P16 && EPI == EPI_QKV_ROPE) wave_epilogue_qkv_p16<2, 2>(p, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
+        else if constexpr (P16 && EPI == EPI_SWIGLU) wave_epilogue_swiglu_p16<2, 2>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
+        else if constexpr (STAGED_EPI(EPI)) staged_epilogue<EPI, 2, 2>(p, g, acc, reinterpret_cast<float*>(lds), row0, rows_end, n0, tid, wr, wc, frow, fk);
         else wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
     }
     if constexpr (EPI == EPI_F32) {
@@ -698,7 +800,7 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
         if (slot >= rows_end) slot = row0;
         asrc[0][i] = p.Hs + (int64_t)slot * p.ldh + c * 8;                    // caption half: the pair slots ARE the caption slots
         asrc[1][i] = p.Hs + (int64_t)p.pair_pa[slot] * p.ldh + c * 8;         // acoustic half: gathered
-        int nrow = n0 + r;
+        int nrow = n0 + p16_src_row(r);                   // P16 column layout: a lane ends up with 16 consecutive output columns
         if (nrow >= p.D) nrow = 0;
         bsrc[0][i] = p.W2 + (int64_t)ec * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
         bsrc[1][i] = p.W2 + (int64_t)(p.E + ea) * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
@@ -777,24 +879,23 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
             const int tok = p.perm[slot];
             const float sc = p.mc[tok], sa = p.ma[tok];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wc * 64 + j * 32 + fk * 16;
+                if (n >= p.D) continue;                                       // D % 16 == 0
+                float o[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wc * 64 + j * 32 + q * 8 + fk * 4;
-                    if (n >= p.D) continue;
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yc = sc * accc[i][j][q * 4 + e];          // what EPI_SCATTER_F32 stored
-                        o[e] = fmaf(sa, acc[i][j][q * 4 + e], yc);            // what EPI_SCATTER_ADD_PLANES added to it
-                    }
-                    store4p(p.out, 0, 1, (int64_t)tok * p.ldc + n, o);
+                for (int e = 0; e < 16; ++e) {
+                    const float yc = sc * accc[i][j][e];                      // what EPI_SCATTER_F32 stored
+                    o[e] = fmaf(sa, acc[i][j][e], yc);                        // what EPI_SCATTER_ADD_PLANES added to it
                 }
+                store8p(p.out, 0, 1, (int64_t)tok * p.ldc + n, o);
+                store8p(p.out, 0, 1, (int64_t)tok * p.ldc + n + 8, o + 8);
+            }
         }
     }
 }
 int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st) {
-    if (a.H % 64 || a.D % 4 || a.E < 1 || a.E * a.E > 16) VB_FAIL(VB_E_INVALID, "moe_w2_pair: H=%d D=%d E=%d unsupported", a.H, a.D, a.E);
+    if (a.H % 64 || a.D % 16 || a.E < 1 || a.E * a.E > 16) VB_FAIL(VB_E_INVALID, "moe_w2_pair: H=%d D=%d E=%d unsupported", a.H, a.D, a.E);
     PairDev d;
     d.Hs = a.Hs; d.ldh = a.H; d.W2 = a.W2; d.w_stride = (int64_t)a.D * a.H; d.ldw = a.H;
     d.pair_off = a.pair_off; d.perm = a.perm; d.pair_pa = a.pair_pa;
@@ -1334,6 +1435,21 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     if (variant == 3 && d.K % 32 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
     if (variant == 4 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
 #endif
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        // QKV + RoPE: 16 consecutive columns per lane (P16 layout) whenever heads and sections are 16-aligned and no grouping is involved
+        if (d.K % 64 == 0 && d.hd % 16 == 0 && d.D % 16 == 0 && d.N % 16 == 0 && !d.group_off && d.ngroups <= 1 && !vb_tune().qkv_p16_off) {
+            hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 0, true>), grid, dim3(NTHREADS), 0, st, d);
+            return;
+        }
+    }
+    if constexpr (EPI == EPI_SWIGLU) {
+        // SwiGLU (routed w1/w3, gathered rows, grouped): P16 layout, 16-byte hidden stores straight from the accumulators instead of
+        // the LDS-staged slab (no epilogue barriers); ldc and the group's column offset must keep the stores 16-byte aligned
+        if (d.K % 64 == 0 && d.N % 16 == 0 && d.ldc % 8 == 0 && d.c_noff_group % 8 == 0 && !vb_tune().qkv_p16_off) {
+            hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 0, true>), grid, dim3(NTHREADS), 0, st, d);
+            return;
+        }
+    }
     if (d.K % 64 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2>), grid, dim3(NTHREADS), 0, st, d);
     else if (d.K % 32 == 0) hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d);   // K = 96 bands (8 experts)
     else hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d);
