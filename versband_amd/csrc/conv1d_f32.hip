@@ -388,68 +388,59 @@ __global__ void __launch_bounds__(256) conv1d_x3_kernel(const ConvDev p) {
     // into registers (raw values + the per-channel affine of the fused norm), xstore() later applies the pointwise
     // transform, splits to bf16 hi/lo and writes the transposed image xT[plane][t][ci].  The loads of chunk ch+1 are
     // in flight while the taps of chunk ch are multiplied.  A wave owns 4 channel pairs of the 32-channel chunk.
+    // A wave owns 8 CONSECUTIVE channels of the 32-channel chunk and a lane one window position per pass: the global loads stay
+    // coalesced along t (one channel row per instruction) and the transposed image takes ONE 16-byte LDS write per plane and
+    // position (round 3; four 4-byte writes of channel pairs before - 4-way bank-conflicted at the 80-byte row pitch).
     constexpr int NIT = XW / 64;
-    float raw[4][NIT][2];
-    float nsc[4][2], nsh[4][2];
+    float raw[8][NIT];
+    float nsc[8], nsh[8];
     auto xload = [&](int c0) {
 #pragma unroll
-        for (int cpi = 0; cpi < 4; ++cpi) {
-            const int ci0 = c0 + 2 * (wave + 4 * cpi);
+        for (int e = 0; e < 8; ++e) {
+            const int ci = c0 + 8 * wave + e;
+            const bool cok = ci < p.Ci;
+            nsc[e] = 1.f; nsh[e] = 0.f;
+            if (cok && (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN)) {
+                const int grp = ci / cpg;
+                const float rs = p.gn_rstd[b * p.gn_groups + grp] * p.gn_gamma[ci];
+                nsc[e] = rs;
+                nsh[e] = p.gn_beta[ci] - p.gn_mean[b * p.gn_groups + grp] * rs;
+            }
+            const float* xrow = xbase + (int64_t)(cok ? ci : 0) * p.T_in;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int ci = ci0 + e;
-                const bool cok = ci < p.Ci;
-                nsc[cpi][e] = 1.f; nsh[cpi][e] = 0.f;
-                if (cok && (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN)) {
-                    const int grp = ci / cpg;
-                    const float rs = p.gn_rstd[b * p.gn_groups + grp] * p.gn_gamma[ci];
-                    nsc[cpi][e] = rs;
-                    nsh[cpi][e] = p.gn_beta[ci] - p.gn_mean[b * p.gn_groups + grp] * rs;
-                }
-                const float* xrow = xbase + (int64_t)(cok ? ci : 0) * p.T_in;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int idx = n0 + in_off + lane + 64 * it;
-                    const bool ok = cok && (lane + 64 * it) < xw_used && idx >= 0 && idx < T_eff;
-                    raw[cpi][it][e] = ok ? xrow[p.upsample2 ? (idx >> 1) : idx * p.in_stride + p.in_phase] : 0.f;
-                }
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = n0 + in_off + lane + 64 * it;
+                const bool ok = cok && (lane + 64 * it) < xw_used && idx >= 0 && idx < T_eff;
+                raw[e][it] = ok ? xrow[p.upsample2 ? (idx >> 1) : idx * p.in_stride + p.in_phase] : 0.f;
             }
         }
     };
     auto xstore = [&](int c0) {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int cpi = 0; cpi < 4; ++cpi) {
-            const int cp = wave + 4 * cpi;
-            const int ci0 = c0 + 2 * cp;
+        for (int it = 0; it < NIT; ++it) {
+            const int wpos = lane + 64 * it;
+            if (wpos >= xw_used) continue;
+            const int idx = n0 + in_off + wpos;
+            const bool inr = idx >= 0 && idx < T_eff;
+            bf16x8 hi, lo;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int wpos = lane + 64 * it;
-                if (wpos >= xw_used) continue;
-                const int idx = n0 + in_off + wpos;
-                const bool inr = idx >= 0 && idx < T_eff;
-                float v[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float t = raw[cpi][it][e];
-                    if (inr && (ci0 + e) < p.Ci) {         // zero padding stays zero: the conv pads the ACTIVATED tensor
-                        if (p.in_act == ACT_LRELU) {
-                            t = t > 0.f ? t : t * p.in_slope;
-                        } else if (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN) {
-                            t = t * nsc[cpi][e] + nsh[cpi][e];
-                            if (p.in_act == ACT_GN_SWISH) t = t / (1.f + __expf(-t));
-                        }
-                    } else {
-                        t = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                float t = raw[e][it];
+                if (inr && (c0 + 8 * wave + e) < p.Ci) {         // zero padding stays zero: the conv pads the ACTIVATED tensor
+                    if (p.in_act == ACT_LRELU) {
+                        t = t > 0.f ? t : t * p.in_slope;
+                    } else if (p.in_act == ACT_GN_SWISH || p.in_act == ACT_GN) {
+                        t = t * nsc[e] + nsh[e];
+                        if (p.in_act == ACT_GN_SWISH) t = t / (1.f + __expf(-t));
                     }
-                    v[e] = t;
+                } else {
+                    t = 0.f;
                 }
-                bf16x2 hi, lo;
-                hi[0] = f2bf(v[0]); hi[1] = f2bf(v[1]);
-                lo[0] = f2bf(v[0] - bf2f(hi[0])); lo[1] = f2bf(v[1] - bf2f(hi[1]));
-                *reinterpret_cast<bf16x2*>(&xT[0][wpos * CKP3 + 2 * cp]) = hi;
-                *reinterpret_cast<bf16x2*>(&xT[1][wpos * CKP3 + 2 * cp]) = lo;
+                hi[e] = f2bf(t);
+                lo[e] = f2bf(t - bf2f(hi[e]));
             }
+            *reinterpret_cast<bf16x8*>(&xT[0][wpos * CKP3 + 8 * wave]) = hi;
+            *reinterpret_cast<bf16x8*>(&xT[1][wpos * CKP3 + 8 * wave]) = lo;
         }
     };
 

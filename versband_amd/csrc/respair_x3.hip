@@ -81,46 +81,38 @@ __global__ void __launch_bounds__(256) respair_x3_kernel(const PairDev p) {
         }
     };
     // activation window staging in two halves (loads of the next chunk fly while the taps of this one are multiplied)
+    // (a wave owns 8 CONSECUTIVE channels of the chunk, a lane one window position per pass: coalesced loads along t, ONE 16-byte
+    //  LDS write per plane and position - four bank-conflicted 4-byte writes of channel pairs before round 3)
     constexpr int NIT = RP_XW / 64;
-    float raw[4][NIT][2];
+    float raw[8][NIT];
     auto xload = [&](int c0) {
 #pragma unroll
-        for (int cpi = 0; cpi < 4; ++cpi) {
-            const int ci0 = c0 + 2 * (wave + 4 * cpi);
+        for (int e = 0; e < 8; ++e) {
+            const float* xrow = xb + (int64_t)(c0 + 8 * wave + e) * p.T;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float* xrow = xb + (int64_t)(ci0 + e) * p.T;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int wpos = lane + 64 * it;
-                    const int idx = x0 + wpos;
-                    const bool ok = wpos < xw_used && idx >= 0 && idx < p.T;
-                    raw[cpi][it][e] = ok ? xrow[idx] : 0.f;
-                }
+            for (int it = 0; it < NIT; ++it) {
+                const int wpos = lane + 64 * it;
+                const int idx = x0 + wpos;
+                const bool ok = wpos < xw_used && idx >= 0 && idx < p.T;
+                raw[e][it] = ok ? xrow[idx] : 0.f;
             }
         }
     };
     auto xstore = [&]() {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int cpi = 0; cpi < 4; ++cpi) {
-            const int cp = wave + 4 * cpi;
+        for (int it = 0; it < NIT; ++it) {
+            const int wpos = lane + 64 * it;
+            if (wpos >= xw_used) continue;
+            bf16x8 hi, lo;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int wpos = lane + 64 * it;
-                if (wpos >= xw_used) continue;
-                float v[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float t = raw[cpi][it][e];          // out-of-range samples were loaded as 0 and lrelu(0) = 0
-                    v[e] = t > 0.f ? t : t * p.slope;
-                }
-                bf16x2 hi, lo;
-                hi[0] = f2bf(v[0]); hi[1] = f2bf(v[1]);
-                lo[0] = f2bf(v[0] - bf2f(hi[0])); lo[1] = f2bf(v[1] - bf2f(hi[1]));
-                *reinterpret_cast<bf16x2*>(&xT[0][wpos * RP_P + 2 * cp]) = hi;
-                *reinterpret_cast<bf16x2*>(&xT[1][wpos * RP_P + 2 * cp]) = lo;
+            for (int e = 0; e < 8; ++e) {
+                const float t = raw[e][it];                   // out-of-range samples were loaded as 0 and lrelu(0) = 0
+                const float v = t > 0.f ? t : t * p.slope;
+                hi[e] = f2bf(v);
+                lo[e] = f2bf(v - bf2f(hi[e]));
             }
+            *reinterpret_cast<bf16x8*>(&xT[0][wpos * RP_P + 8 * wave]) = hi;
+            *reinterpret_cast<bf16x8*>(&xT[1][wpos * RP_P + 8 * wave]) = lo;
         }
     };
 
