@@ -15,6 +15,7 @@ from oracle import ref_cpu
 from tests.helpers import SEED, check_digest, clip_batch, describe, exp_noise, gumbel_arrays, gumbel_arrays_steps, rel_l2
 from versband_amd import _lib as L
 from versband_amd import model as vm
+from versband_amd import prng
 from versband_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -365,18 +366,22 @@ def test_fused_band_experts_match_two_gemm_path(ctx, sds, engines, monkeypatch, 
     assert torch.equal(v1, v2), describe("fused vs two-GEMM band experts", v1, v2)
 
 
-@pytest.mark.parametrize("B,T", [(4, 752), (3, 700), (8, 752)])
-def test_single_launch_routed_w2_matches_two_launch_path(engines, monkeypatch, B, T):
-    """bf16 production mode at >= 4096 token rows runs the second product of BOTH routed expert groups as ONE launch over (caption,
-    acoustic) pair buckets (moe_w2_pair_kernel: K = 2H, the caption half's accumulator parked at the midpoint, fmaf(m_a, acc_a, m_c *
-    acc_c) in the epilogue) instead of scatter-fp32 + scatter-add: the same k order per half and the same two roundings, so the DiT
-    output and the routes must be bit-identical to the two-launch path (VB_W2_PAIR=0), incl. ragged pair buckets (T = 700)."""
+@pytest.mark.parametrize("B,T,mode", [(4, 752, "1"), (3, 700, "1"), (8, 752, "1"), (8, 752, "2"), (4, 752, "3")])
+def test_single_launch_routed_w2_matches_two_launch_path(engines, sds, monkeypatch, B, T, mode):
+    """bf16 production mode at >= 4096 token rows runs the second product of BOTH routed expert groups as ONE plain GEMM over
+    (caption, acoustic) pair buckets (moe_w2_pair_kernel: K = 2H; the gate weights m_c / m_a are folded into the hidden rows by the
+    SwiGLU epilogue before their bf16 rounding) instead of scatter-fp32 + scatter-add.  Same mathematics, one rounding placed
+    differently (bf16(m h) against m * bf16(h)): the DiT output must agree with the two-launch path (VB_W2_PAIR=0) to bf16 rounding
+    noise, block 0 must route identically (its routing does not see the change), and both stay equally close to the fp32 oracle.
+    VB_W2_PAIR=2 / 3 force the 128 x 128 / 128 x 192 tile (ragged pair buckets at T = 700)."""
     eng = engines[(4, "bf16")]
     Lc = 80
     inp = clip_batch(B, T, Lc)
     cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
     t_idx = torch.full((2 * B,), 555, dtype=torch.int64)
     assert 2 * B * T >= 4096
+    monkeypatch.setenv("VB_W2_PAIR", mode)
+    L.load().vb_tune_reload()
     v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=9, return_routes=True)
     torch.cuda.synchronize()
     v1, r1 = v1.clone(), r1.clone()
@@ -387,15 +392,31 @@ def test_single_launch_routed_w2_matches_two_launch_path(engines, monkeypatch, B
     monkeypatch.delenv("VB_W2_PAIR")
     L.load().vb_tune_reload()
     assert torch.isfinite(v1).all()
-    assert torch.equal(r1, r2)
-    assert torch.equal(v1, v2), describe("single-launch pair w2 vs two launches", v1, v2)
+    assert torch.equal(r1[0], r2[0]), "block 0 routes must not depend on how w2 is launched"
+    flips = float((r1 != r2).float().mean())
+    err = rel_l2(v1, v2)
+    print(f"pair w2 (mode {mode}) vs two launches: rel_l2 {err:.3e}, route flips {flips:.2e}")
+    assert err < 2e-3 and flips < 1e-3, describe("single-launch pair w2 vs two launches", v1, v2)
+    if B == 4 and mode == "1":
+        # against the fp32 oracle on the same device-drawn noise: both forms are bf16 evaluations of the same sums
+        noise = [tuple(torch.from_numpy(np.concatenate([prng.device_router_exponentials(9, c, 0, br, blk, gate, T, w) for c in range(B)]))
+                       for gate, w in ((0, 2), (1, 4), (2, 4))) for br in (0, 1) for blk in range(4)]
+        sd = sds[4]
+        for br, key in ((0, "t5_cond"), (1, "t5_uncond")):
+            c = ref_cpu.dit_precompute(sd, inp[key], inp["midi"], inp["beats"], T)
+            ref = ref_cpu.dit_forward(sd, inp["x_latent"], t_idx[:B], c, noise[br * 4:(br + 1) * 4])
+            e1, e2 = rel_l2(v1[br * B:(br + 1) * B], ref), rel_l2(v2[br * B:(br + 1) * B], ref)
+            print(f"  branch {br}: vs oracle pair {e1:.3e}, two-launch {e2:.3e}")
+            assert e1 < 5e-3 and e1 < 1.5 * e2 + 1e-4
 
 
+@pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_NO_XCD_GROUPS"])
 @pytest.mark.parametrize("prec,B,T", [("bf16", 4, 752), ("split", 3, 700)])
-def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T):
+def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T, knob):
     """The QKV + RoPE GEMM fills its weight tile with permuted source rows so a lane's accumulator holds 16 CONSECUTIVE output columns
     (16-byte q / k stores and RoPE-table loads instead of 8-byte ones): the same values in other lanes - the DiT output must not change
-    by a bit against the quad layout (VB_QKV_P16_OFF=1), in both precisions, full and ragged row tiles."""
+    by a bit against the quad layout (VB_QKV_P16_OFF=1), in both precisions, full and ragged row tiles.  Same for the XCD-affine
+    tile order of the per-clip grouped caption-gate GEMM (VB_NO_XCD_GROUPS=1 restores the interleaved order): same tiles, other CUs."""
     eng = engines[(4, prec)]
     Lc = 80
     inp = clip_batch(B, T, Lc)
@@ -404,11 +425,11 @@ def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T
     v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
     torch.cuda.synchronize()
     v1, r1 = v1.clone(), r1.clone()
-    monkeypatch.setenv("VB_QKV_P16_OFF", "1")
+    monkeypatch.setenv(knob, "1")
     L.load().vb_tune_reload()
     v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
     torch.cuda.synchronize()
-    monkeypatch.delenv("VB_QKV_P16_OFF")
+    monkeypatch.delenv(knob)
     L.load().vb_tune_reload()
     assert torch.isfinite(v1).all() and torch.equal(r1, r2)
     assert torch.equal(v1, v2), describe("P16 vs quad column layout of the QKV epilogue", v1, v2)

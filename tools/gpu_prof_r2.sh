@@ -8,7 +8,7 @@ R=$PWD
 O=$R/gpurun_out/$TAG
 cd /tmp
 prof() { # name args
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-isolated $2 > $O/$1.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$1 -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-isolated --no-pmc --no-parity-check $2 > $O/$1.log 2>&1
   f=$(find $O/$1 -name "*kernel_stats.csv" | head -1)
   cp "$f" $O/${1}_kernel_stats.csv
   tail -2 $O/$1.log | cut -c1-300
@@ -20,7 +20,7 @@ prof stream1 "--streams 1"
 prof batch1 "--streams 1 --batch 1"
 if [ "${2:-}" = "pmc" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$c -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-isolated --streams 1 > $O/$c.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$c -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-isolated --no-pmc --no-parity-check --streams 1 > $O/$c.log 2>&1
   echo "$c exit $?"
 done
 cd $R

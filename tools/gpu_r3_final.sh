@@ -1,0 +1,31 @@
+#!/bin/bash
+# round-3 evidence: whole GPU suite, smoke, bench lines (c2 default incl. live PMC, c3, c5, b1, b2, one stream, fp32 vocoder),
+# rocprofv3 kernel stats (default / one stream / batch 1), SQ counter pass
+set -u
+TAG=${1:-r3z}
+mkdir -p gpurun_out/$TAG
+export TMPDIR=/tmp
+O=gpurun_out/$TAG
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $O/gpu_tests.log 2>&1
+echo "gpu tests exit: $?" >> $O/gpu_tests.log
+tail -6 $O/gpu_tests.log
+timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -2 | tee $O/smoke.log
+timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
+timeout 400 python bench.py --vocoder-precision fp32 --no-cpu-baseline --no-pmc > $O/bench_c2_fp32voc.json 2> $O/bench_c2_fp32voc.err
+timeout 400 python bench.py --workload c3 --steps 1 --warmup 1 > $O/bench_c3.json 2> $O/bench_c3.err
+timeout 400 python bench.py --workload c5 --steps 1 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err
+timeout 300 python bench.py --batch 1 --streams 1 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_b1.json 2> $O/bench_b1.err
+timeout 300 python bench.py --batch 2 --streams 1 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_b2.json 2> $O/bench_b2.err
+timeout 300 python bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $O/bench_s1.json 2> $O/bench_s1.err
+for f in c2 c2_fp32voc c3 c5 b1 b2 s1; do python - <<PY
+import json
+try:
+    d=json.loads([l for l in open('$O/bench_$f.json') if l.startswith('{')][-1])
+    print('$f', 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],2), 'frac', round(d['roofline']['frac'],4), 'parity', d['parity_check'] and d['parity_check']['ok'], d['config']['sampler_loop'], d['device']['clocks_during_timed_region'].get('sclk_mhz_avg'))
+    for r in d['roofline']['classes']: print('   ', r['class'][:44], round(r['ms_per_pass'],2), 'ms', round(r['avg_launch_us'],1),'us', round(r['frac_of_mfma_peak'],4), r['launches_per_pass'])
+except Exception as e:
+    print('$f', 'FAILED', e)
+PY
+done
+bash tools/gpu_prof_r2.sh $TAG/prof 2>&1 | grep -v "simple_timer" | tail -60
+bash tools/gpu_sq_pmc.sh $TAG 2>&1 | tail -30

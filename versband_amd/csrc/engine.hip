@@ -36,6 +36,7 @@ static void tune_load() {
     t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr; t.moe_unfused = getenv("VB_MOE_UNFUSED") != nullptr;
     t.w2_pair = env_int("VB_W2_PAIR", 1);
     t.qkv_p16_off = getenv("VB_QKV_P16_OFF") != nullptr;
+    t.no_xcd_groups = getenv("VB_NO_XCD_GROUPS") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
@@ -498,7 +499,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
             g = GemmArgs();
             g.A = u.p; g.a_plane = ND; g.lda = D; g.B = cd.mf[i]; g.b_plane = (int64_t)Beff * cd.NS * D; g.ldb = D;
             g.b_group_stride = (int64_t)cd.NS * D; g.M = N; g.N = cd.NS; g.K = D; g.nseg = nseg; g.ngroups = Beff;
-            g.group_off = cd.clip_off; g.epi = EPI_F32; g.bias = cd.cb[i]; g.bias_group_stride = cd.NS; g.out32 = s.y32; g.ldc32 = cd.NS;
+            g.group_off = cd.clip_off; g.group_rows = T; g.epi = EPI_F32; g.bias = cd.cb[i]; g.bias_group_stride = cd.NS; g.out32 = s.y32; g.ldc32 = cd.NS;
             VB_TRY(launch_gemm(g, st));
         } else {
         g = GemmArgs();
@@ -530,11 +531,12 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         g.A = u.p; g.a_plane = ND; g.lda = D; g.a_rows = s.perm; g.B = (const bf16_t*)bw.w13; g.b_plane = (int64_t)2 * E * 2 * H * D;
         g.ldb = D; g.b_group_stride = (int64_t)2 * H * D; g.M = 2 * N; g.N = 2 * H; g.K = D; g.nseg = nseg; g.ngroups = 2 * E;
         g.group_off = s.group_off; g.epi = EPI_SWIGLU; g.out = Hs; g.ldc = H;
+        if (w2_pair) { g.row_scale = s.mc; g.row_scale2 = s.ma; g.scale_split = N; }      // gate weights ride in the hidden rows
         VB_TRY(launch_gemm(g, st));
         if (w2_pair) {
             MoeW2PairArgs pw;
             pw.Hs = Hs.p; pw.W2 = (const bf16_t*)bw.w2; pw.pair_off = s.pair_off; pw.perm = s.perm; pw.pair_pa = s.pair_pa;
-            pw.mc = s.mc; pw.ma = s.ma; pw.out = y.p; pw.N = N; pw.D = D; pw.H = H; pw.E = E;
+            pw.out = y.p; pw.N = N; pw.D = D; pw.H = H; pw.E = E;
             VB_TRY(launch_moe_w2_pair(pw, st));
         } else {
         // y = m_c * FFN^c(u)  (store), then y += m_a * FFN^a(u) (planes out)

@@ -37,6 +37,8 @@ struct GemmDev {
     float* out32; int ldc32;
     const float* gate; int gate_ld; int T;
     const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
+    const float* row_scale2; int scale_split;
+    int grp_rows, grp_tiles;        // uniform groups (per-clip operands): rows per group, row tiles per group; 0 = off
     int ncc, rpx;                   // 128x128 kernel, wide N: column tiles are visited in chunks of ncc (0 = off) over the rpx row tiles of an XCD
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
@@ -306,13 +308,18 @@ __device__ __forceinline__ void wave_epilogue_swiglu_p16(const GemmDev& p, int g
     for (int i = 0; i < TM; ++i) {
         const int m = row_base + i * 32 + frow;
         if (m >= rows_end) continue;
+        float gs = 1.f;
+        if (p.row_scale2) gs = (m < p.scale_split ? p.row_scale : p.row_scale2)[p.a_rows[m]];     // routed gate weight of this slot's token
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n_base + j * 32 + fk * 16;
             if (n >= p.N) continue;                          // N % 16 == 0 is required on this path
             float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = silu_f(acc[i][j][2 * e]) * acc[i][j][2 * e + 1];
+            for (int e = 0; e < 8; ++e) {
+                o[e] = silu_f(acc[i][j][2 * e]) * acc[i][j][2 * e + 1];
+                if (p.row_scale2) o[e] *= gs;
+            }
             store8p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + (n >> 1), o);
         }
     }
@@ -606,7 +613,14 @@ gemm_bf16_glds_kernel(const GemmDev p) {
             rt = jx / nN;
         }
         int tmg = rt * 8 + (L & 7);
-        if (p.group_off) {
+        if (p.grp_rows > 0) {
+            // uniform groups with per-group B operands (caption-gate scores: one folded key matrix per clip): XCD x = L & 7 serves the
+            // groups x, x + 8, ... - all row tiles of a group on one XCD, its B operand in one L2 (it was fetched by all eight)
+            g = (L & 7) + 8 * (rt / p.grp_tiles);
+            if (g >= p.ngroups) return;
+            row0 = g * p.grp_rows + (rt % p.grp_tiles) * BM; rows_end = (g + 1) * p.grp_rows;
+            if (row0 >= rows_end) return;
+        } else if (p.group_off) {
             bool found = false;
             for (int gi = 0; gi < p.ngroups; ++gi) {
                 int lo = p.group_off[gi], hi = p.group_off[gi + 1];
@@ -746,23 +760,26 @@ gemm_bf16_glds_kernel(const GemmDev p) {
 // The two w2 GEMMs (caption group: scatter m_c * H_c W2c^T as fp32; acoustic group: read it back, add m_a * H_a W2a^T, write bf16
 // planes) round-tripped a [N][768] fp32 partial sum through HBM: 37 MB written + 37 MB re-read per block evaluation at 8 clips, for
 // two launches at 10-13 % of the MFMA peak.  Here the tokens are bucketed by their (caption expert, acoustic expert) PAIR (E*E groups,
-// bucket_place_kernel: the caption slots ARE the pair slots) and ONE grouped launch walks K = 2H: first half A = the tile's own rows of
-// the routed hidden tensor (caption slots, contiguous) against W2c[c], second half A = the tokens' acoustic-slot rows (gathered)
-// against W2a[a].  The per-token gate weights
-// differ between the halves, so the first half's accumulator is parked in registers at the K midpoint and the epilogue forms
-// fmaf(m_a, acc_a, m_c * acc_c) - the same two roundings, in the same order, as the two-launch path: bit-identical (test).
-// Same tile / ring / swizzle as gemm_bf16_glds_kernel<*, 64, 2> (128 x 128 x 64, two workgroups per CU).
+// bucket_place_kernel: the caption slots ARE the pair slots) and ONE grouped launch walks K = 2H as a plain GEMM: first half A = the
+// tile's own rows of the routed hidden tensor (caption slots, contiguous) against W2c[c], second half A = the tokens' acoustic-slot
+// rows (gathered) against W2a[a].  The per-token gate weights m_c / m_a ride in the hidden rows (folded in by the SwiGLU epilogue
+// before the bf16 rounding - the same relative rounding error as scaling the fp32 product afterwards), so one accumulator serves.
+// Tile 128 x (64 TN): 128 x 192 when that brings the launch from two rounds of the CUs down to one (8 clips: 110 row tiles x 4
+// = 440 workgroups at two per CU), 128 x 128 otherwise.  Ring / swizzle / P16 column layout as in gemm_bf16_glds_kernel<*, 64, 2>.
 struct PairDev {
     const bf16_t* Hs; int ldh;                               // routed hidden [2N][H] bf16, slot order (caption slots, then acoustic slots)
     const bf16_t* W2; int64_t w_stride; int ldw;             // [2E][D][H]
     const int* pair_off; const int* perm; const int* pair_pa;   // pair slot p: caption row = p, acoustic row = pair_pa[p], token = perm[p]
-    const float* mc; const float* ma;
     bf16_t* out; int ldc;                                    // y planes [N][D] (one plane: bf16 production mode)
     int N, D, H, E, n_tiles;
 };
-__global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) {
-    constexpr int BKT = 64, NST = 2, CH = 8, RS = 8, SPW = 4, LPT = 2 * SPW, OPB = BM * BKT * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * 2 * OPB];
+template <int TN>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) moe_w2_pair_kernel(const PairDev p) {
+    constexpr int BKT = 64, NST = 2, CH = 8, RS = 8;
+    constexpr int BNP = 64 * TN;                             // columns per tile
+    constexpr int SPA = 4, SPB = BNP / 32;                   // 1-KB DMA pieces per wave: A (128 rows), B (BNP rows)
+    constexpr int ABYTES = BM * BKT * 2, BBYTES = BNP * BKT * 2, STAGE = ABYTES + BBYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -785,47 +802,51 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
         if (!found) return;
     }
     const int ec = g / p.E, ea = g - ec * p.E;
-    const int n0 = tile_n * BN;
+    const int n0 = tile_n * BNP;
     const int KT = p.H / BKT;
     const int total = 2 * KT;
 
-    const bf16_t* asrc[2][SPW]; const bf16_t* bsrc[2][SPW];
+    const bf16_t* asrc[2][SPA]; const bf16_t* bsrc[SPB];     // B: one pointer per piece, the expert half is a uniform offset
+    const int64_t boff1 = (int64_t)(p.E + ea - ec) * p.w_stride;
 #pragma unroll
-    for (int i = 0; i < SPW; ++i) {
-        const int s = wave * SPW + i;
-        const int r = RS * s + lane / CH;
-        const int cs = lane % CH;
-        const int c = cs ^ ((r >> 1) & 7);
+    for (int i = 0; i < SPA; ++i) {
+        const int r = RS * (wave * SPA + i) + lane / CH;
+        const int c = (lane % CH) ^ ((r >> 1) & 7);
         int slot = row0 + r;
         if (slot >= rows_end) slot = row0;
         asrc[0][i] = p.Hs + (int64_t)slot * p.ldh + c * 8;                    // caption half: the pair slots ARE the caption slots
         asrc[1][i] = p.Hs + (int64_t)p.pair_pa[slot] * p.ldh + c * 8;         // acoustic half: gathered
+    }
+#pragma unroll
+    for (int i = 0; i < SPB; ++i) {
+        const int r = RS * (wave * SPB + i) + lane / CH;
+        const int c = (lane % CH) ^ ((r >> 1) & 7);
         int nrow = n0 + p16_src_row(r);                   // P16 column layout: a lane ends up with 16 consecutive output columns
         if (nrow >= p.D) nrow = 0;
-        bsrc[0][i] = p.W2 + (int64_t)ec * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
-        bsrc[1][i] = p.W2 + (int64_t)(p.E + ea) * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
+        bsrc[i] = p.W2 + (int64_t)ec * p.w_stride + (int64_t)nrow * p.ldw + c * 8;
     }
     auto issue = [&](int t) {
         const int st = t % NST;
         const int half = t >= KT ? 1 : 0;
         const int k0 = (t - half * KT) * BKT;
+        unsigned char* sa = lds + st * STAGE;
 #pragma unroll
-        for (int i = 0; i < SPW; ++i) {
-            const int s = wave * SPW + i;
+        for (int i = 0; i < SPA; ++i) {
             const bf16_t* ap = half ? asrc[1][i] : asrc[0][i];
-            const bf16_t* bp = half ? bsrc[1][i] : bsrc[0][i];
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ap + k0), (lds_ptr_t)(&lds[(st * 2 + 0) * OPB + s * 1024]), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bp + k0), (lds_ptr_t)(&lds[(st * 2 + 1) * OPB + s * 1024]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ap + k0), (lds_ptr_t)(sa + (wave * SPA + i) * 1024), 16, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < SPB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + (half ? boff1 : 0) + k0), (lds_ptr_t)(sa + ABYTES + (wave * SPB + i) * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[2][2], accc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     issue(0);
     const int frow = lane & 31, fk = lane >> 5;
@@ -834,26 +855,15 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();           // tile t landed everywhere; everyone finished reading stage (t-1)%NST
         if (t + 1 < total) issue(t + 1);
-        if (t == KT) {                          // K midpoint: park the caption product, start the acoustic one
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    accc[i][j] = acc[i][j];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-                }
-        }
-        const unsigned char* As = &lds[(st * 2 + 0) * OPB];
-        const unsigned char* Bs = &lds[(st * 2 + 1) * OPB];
-        bf16x8 af[2][2], bf[2][2];
+        const unsigned char* As = lds + st * STAGE;
+        const unsigned char* Bs = As + ABYTES;
+        bf16x8 af[2][2], bf[2][TN];
         auto fload = [&](int ks, int slot) {
             const int c = ks * 2 + fk;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
-                bf[slot][i] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 64 + i * 32 + frow, c));
-            }
+            for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 32 * TN + j * 32 + frow, c));
         };
         fload(0, 0);
 #pragma unroll
@@ -864,33 +874,26 @@ __global__ void __launch_bounds__(NTHREADS) moe_w2_pair_kernel(const PairDev p) 
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // epilogue: a lane owns one token row and 4 consecutive columns per accumulator quad
-    {
-#pragma clang fp contract(off)
+    // epilogue: a lane owns one token row and 16 consecutive columns per 32 x 32 tile (P16 layout): 16-byte stores
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int slot = row0 + wr * 64 + i * 32 + frow;
-            if (slot >= rows_end) continue;
-            const int tok = p.perm[slot];
-            const float sc = p.mc[tok], sa = p.ma[tok];
+    for (int i = 0; i < 2; ++i) {
+        const int slot = row0 + wr * 64 + i * 32 + frow;
+        if (slot >= rows_end) continue;
+        const int tok = p.perm[slot];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wc * 64 + j * 32 + fk * 16;
-                if (n >= p.D) continue;                                       // D % 16 == 0
-                float o[16];
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wc * 32 * TN + j * 32 + fk * 16;
+            if (n >= p.D) continue;                                       // D % 16 == 0
+            float o[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float yc = sc * accc[i][j][e];                      // what EPI_SCATTER_F32 stored
-                    o[e] = fmaf(sa, acc[i][j][e], yc);                        // what EPI_SCATTER_ADD_PLANES added to it
-                }
-                store8p(p.out, 0, 1, (int64_t)tok * p.ldc + n, o);
-                store8p(p.out, 0, 1, (int64_t)tok * p.ldc + n + 8, o + 8);
-            }
+            for (int e = 0; e < 16; ++e) o[e] = acc[i][j][e];
+            store8p(p.out, 0, 1, (int64_t)tok * p.ldc + n, o);
+            store8p(p.out, 0, 1, (int64_t)tok * p.ldc + n + 8, o + 8);
         }
     }
 }
@@ -899,11 +902,18 @@ int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st) {
     PairDev d;
     d.Hs = a.Hs; d.ldh = a.H; d.W2 = a.W2; d.w_stride = (int64_t)a.D * a.H; d.ldw = a.H;
     d.pair_off = a.pair_off; d.perm = a.perm; d.pair_pa = a.pair_pa;
-    d.mc = a.mc; d.ma = a.ma; d.out = a.out; d.ldc = a.D; d.N = a.N; d.D = a.D; d.H = a.H; d.E = a.E;
-    d.n_tiles = cdiv(a.D, BN);
+    d.out = a.out; d.ldc = a.D; d.N = a.N; d.D = a.D; d.H = a.H; d.E = a.E;
     const int mt = cdiv(a.N, BM) + a.E * a.E;                    // upper bound of the row tiles over all pair groups
     ProfScope prof(0, 2.0 * a.N * a.D * 2.0 * a.H, 2.0 * a.N * a.H * 2.0 + 2.0 * a.E * a.D * a.H * 2.0 + (double)a.N * a.D * 2.0, st);
-    hipLaunchKernelGGL(moe_w2_pair_kernel, dim3(d.n_tiles * ((mt + 7) / 8 * 8)), dim3(NTHREADS), 0, st, d);
+    // 128 x 192 tiles when 128 x 128 would need a second round of the 512 workgroup slots (two per CU) and 192-wide tiles do not
+    const int wide = vb_tune().w2_pair == 3 || (vb_tune().w2_pair == 1 && a.D % 192 == 0 && mt * cdiv(a.D, 128) > 512 && mt * (a.D / 192) <= 512);
+    if (wide) {
+        d.n_tiles = a.D / 192;
+        hipLaunchKernelGGL(moe_w2_pair_kernel<3>, dim3(d.n_tiles * ((mt + 7) / 8 * 8)), dim3(NTHREADS), 0, st, d);
+    } else {
+        d.n_tiles = cdiv(a.D, BN);
+        hipLaunchKernelGGL(moe_w2_pair_kernel<2>, dim3(d.n_tiles * ((mt + 7) / 8 * 8)), dim3(NTHREADS), 0, st, d);
+    }
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
@@ -1445,7 +1455,7 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     if constexpr (EPI == EPI_SWIGLU) {
         // SwiGLU (routed w1/w3, gathered rows, grouped): P16 layout, 16-byte hidden stores straight from the accumulators instead of
         // the LDS-staged slab (no epilogue barriers); ldc and the group's column offset must keep the stores 16-byte aligned
-        if (d.K % 64 == 0 && d.N % 16 == 0 && d.ldc % 8 == 0 && d.c_noff_group % 8 == 0 && !vb_tune().qkv_p16_off) {
+        if (d.K % 64 == 0 && d.N % 16 == 0 && d.ldc % 8 == 0 && d.c_noff_group % 8 == 0 && (!vb_tune().qkv_p16_off || d.row_scale2)) {
             hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 0, true>), grid, dim3(NTHREADS), 0, st, d);
             return;
         }
@@ -1867,7 +1877,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.c_noff_group = a.c_noff_group; d.bias = a.bias; d.bias_group_stride = a.bias_group_stride;
     d.out = a.out.p; d.out_plane = a.out.plane; d.out_np = a.out.np; d.ldc = a.ldc;
     d.out32 = a.out32; d.ldc32 = a.ldc32; d.gate = a.gate; d.gate_ld = a.gate_ld; d.T = a.T > 0 ? a.T : 1;
-    d.rows_out = a.rows_out; d.row_scale = a.row_scale; d.y32_in = a.y32_in;
+    d.rows_out = a.rows_out; d.row_scale = a.row_scale; d.y32_in = a.y32_in; d.row_scale2 = a.row_scale2; d.scale_split = a.scale_split;
     d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
     d.qkv_np = a.q.np; d.rope_cos = a.rope_cos; d.rope_sin = a.rope_sin; d.H = a.H; d.hd = a.hd > 0 ? a.hd : 1;
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
@@ -1933,6 +1943,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
+    d.grp_rows = 0; d.grp_tiles = 0;
+    if (!cfg && a.group_off && a.group_rows > 0 && a.K % 32 == 0 && !vb_tune().no_xcd_groups) {      // 128 x 128 DMA kernels only
+        d.grp_rows = a.group_rows; d.grp_tiles = cdiv(a.group_rows, BM);
+        mt = cdiv(a.ngroups, 8) * 8 * d.grp_tiles;
+    }
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
     d.ncc = 0; d.rpx = (mt + 7) / 8;
     if (!cfg && !a.group_off) {       // VB_GEMM_NCHUNK=c (tuning, default off until measured in the pipeline): column chunking for wide N

@@ -28,6 +28,9 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int nseg = 1;                     // 1 = plain bf16, 3 = bf16x3 split precision
     int ngroups = 1; const int* group_off = nullptr;   // device [ngroups+1] slot offsets (null: one group [0,M))
+    int group_rows = 0;               // > 0 (with group_off): every group has exactly this many rows (group g = rows [g R, (g+1) R): per-clip
+                                      // operands) - the 128 x 128 kernel then keeps all tiles of a group on ONE XCD (group g -> XCD g % 8), so
+                                      // a group's B operand is fetched into one L2 instead of all eight
     int c_noff_group = 0;             // output column offset per group
     int epi = EPI_F32;
     const float* bias = nullptr; int64_t bias_group_stride = 0;
@@ -35,17 +38,21 @@ struct GemmArgs {
     float* out32 = nullptr; int ldc32 = 0;
     const float* gate = nullptr; int gate_ld = 0; int T = 1;
     const int* rows_out = nullptr; const float* row_scale = nullptr; const float* y32_in = nullptr;
+    // EPI_SWIGLU only: per-row gate weight folded into the hidden value BEFORE its bf16 rounding (rows < scale_split take
+    // row_scale[a_rows[m]], the others row_scale2[a_rows[m]]): lets the routed w2 product run as one plain K-concatenated GEMM
+    const float* row_scale2 = nullptr; int scale_split = 0;
     Planes q = {nullptr, 0, 1}, k = {nullptr, 0, 1}, vt = {nullptr, 0, 1};
     const float* rope_cos = nullptr; const float* rope_sin = nullptr;
     int H = 1, hd = 1, Tpad = 0, D = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // routed experts, second product of BOTH groups in one launch over (caption, acoustic) pair buckets (bf16, E <= 4; moe_w2_pair_kernel):
-// out[tok][:] = m_c[tok] * (Hs[caption slot] W2[c]^T) + m_a[tok] * (Hs[acoustic slot] W2[E + a]^T), bit-identical to the two-launch path
+// out[tok][:] = Hs[caption slot] W2[c]^T + Hs[acoustic slot] W2[E + a]^T  with the gate weights m_c / m_a already folded into the
+// hidden rows by the SwiGLU epilogue (GemmArgs::row_scale / row_scale2): one accumulator, K = 2H
 struct MoeW2PairArgs {
-    const bf16_t* Hs = nullptr; const bf16_t* W2 = nullptr;     // [2N][H] bf16 slot order; [2E][D][H]
+    const bf16_t* Hs = nullptr; const bf16_t* W2 = nullptr;     // [2N][H] bf16 slot order (gate-scaled); [2E][D][H]
     const int* pair_off = nullptr; const int* perm = nullptr; const int* pair_pa = nullptr;        // launch_bucket pair-mode outputs
-    const float* mc = nullptr; const float* ma = nullptr; bf16_t* out = nullptr;                    // out [N][D] bf16
+    bf16_t* out = nullptr;                                      // out [N][D] bf16
     int N = 0, D = 0, H = 0, E = 0;
 };
 int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st);
