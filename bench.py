@@ -544,9 +544,11 @@ def main():
     def run_worker(w, ks):
         torch.cuda.set_device(device)           # a new host thread starts on device 0: bind it to this rank's GPU
         si = next((i for i, ww in enumerate(workers) if ww is w), 0)
-        if len(cores) >= world * S and hasattr(os, "sched_setaffinity"):
+        import threading
+        if len(cores) >= world * S and hasattr(os, "sched_setaffinity") and threading.current_thread() is not threading.main_thread():
             # one core per (rank, stream) host thread, all distinct on the box: the launch threads of 8 ranks x 2 streams must not
-            # migrate onto each other (pid 0 = the calling thread)
+            # migrate onto each other (pid 0 = the calling thread).  Worker threads only: the main thread keeps the process mask, which
+            # the CPU-baseline child process inherits (pinned, it reported 1 core)
             try:
                 core = cores[(local * S + si) % len(cores)] if world > 1 else cores[si % len(cores)]
                 os.sched_setaffinity(0, {core})

@@ -301,7 +301,7 @@ def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
     cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
     t_idx = torch.full((2 * B,), 321, dtype=torch.int64)
     outs = []
-    for cfg in ("22", "33", "11", "21"):
+    for cfg in ("22", "33", "11", "21", "23"):       # 23 = 128 x 192 two-per-CU gated-residual kernel (other launches keep 128 x 128)
         monkeypatch.setenv("VB_GEMM_TILE", cfg)
         L.load().vb_tune_reload()
         v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
@@ -408,6 +408,33 @@ def test_single_launch_routed_w2_matches_two_launch_path(engines, sds, monkeypat
             e1, e2 = rel_l2(v1[br * B:(br + 1) * B], ref), rel_l2(v2[br * B:(br + 1) * B], ref)
             print(f"  branch {br}: vs oracle pair {e1:.3e}, two-launch {e2:.3e}")
             assert e1 < 5e-3 and e1 < 1.5 * e2 + 1e-4
+
+
+@pytest.mark.parametrize("prec,B,T,nb", [("bf16", 2, 752, 2), ("split", 3, 700, 2), ("split", 2, 333, 1)])
+def test_proj_in_as_gemm_matches_the_conv_launch(engines, monkeypatch, prec, B, T, nb):
+    """proj_in (Conv1d 20 -> 768, k = 5) runs as im2col + split-precision GEMM with the bias / acoustic add in the epilogue and the row
+    written for both CFG branches; VB_PROJ_IN_CONV=1 restores the conv launch.  Both are fp32-class evaluations of the same 100-term
+    sums in another order: the DiT output agrees to fp32 rounding noise and the routes are identical (conditional-only batches too)."""
+    eng = engines[(4, prec)]
+    Lc = 80
+    inp = clip_batch(B, T, Lc)
+    t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]]) if nb == 2 else inp["t5_cond"]
+    cond = eng.precompute_cond(t5, inp["midi"], inp["beats"], T)
+    t_idx = torch.full((nb * B,), 77, dtype=torch.int64)
+    v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=5, return_routes=True)
+    torch.cuda.synchronize()
+    v1, r1 = v1.clone(), r1.clone()
+    monkeypatch.setenv("VB_PROJ_IN_CONV", "1")
+    L.load().vb_tune_reload()
+    v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=5, return_routes=True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("VB_PROJ_IN_CONV")
+    L.load().vb_tune_reload()
+    err = rel_l2(v1, v2)
+    print(f"proj_in GEMM vs conv ({prec}): rel_l2 {err:.3e}, route flips {int((r1 != r2).sum())}")
+    assert torch.isfinite(v1).all()
+    assert err < (2e-3 if prec == "bf16" else 2e-5), describe("proj_in as GEMM vs conv launch", v1, v2)
+    assert int((r1 != r2).sum()) <= (4 if prec == "bf16" else 0)
 
 
 @pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_NO_XCD_GROUPS"])

@@ -81,6 +81,8 @@ struct VbTune {
     bool conv_direct_epi = false, gate_unfolded = false, stem_f32 = false, band_unfused = false, moe_unfused = false, score_fused = false, no_graph = false;
     int w2_pair = 1;
     bool qkv_p16_off = false, no_xcd_groups = false;
+    int wide_resid = 1;
+    bool proj_in_conv = false;
 };
 const VbTune& vb_tune();
 unsigned vb_tune_generation();      // bumped by vb_tune_reload(): anything that bakes knob-dependent kernel choices in (captured graphs) keys on it

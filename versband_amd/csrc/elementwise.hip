@@ -609,6 +609,52 @@ int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, in
 }
 int bucket_scratch_ints(int N, int E) { return cdiv(N, BK_T) * BK_G + 64; }
 
+// ---------------------------------------------------------------------------
+// proj_in (Conv1d C -> D, k taps; vocal2music_moe.py:395) as a GEMM: the latent window of every token as one K-contiguous row
+//   A[plane][m = b*T + t][k = tap*32 + ci] = split-bf16( x[b][ci][t + tap - pad] )   (zero outside the clip, for ci >= C and for k >= taps*32)
+// and the split conv weights [2][taps][D][32] re-laid as B[plane][D][KP].  One thread = one 16-byte group of 8 consecutive k.
+// ---------------------------------------------------------------------------
+__global__ void im2col_latent_kernel(const float* __restrict__ x, int B, int C, int T, int taps, int pad, int KP, bf16_t* __restrict__ out,
+                                     int64_t plane) {
+    const int gpr = KP >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * T * gpr) return;
+    const int m = (int)(idx / gpr), gi = (int)(idx - (int64_t)m * gpr);
+    const int b = m / T, t = m - b * T;
+    const int k0 = gi * 8, tap = k0 >> 5, ci0 = k0 & 31;
+    const int ts = t + tap - pad;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = ci0 + e;
+        const float v = (tap < taps && ci < C && ts >= 0 && ts < T) ? x[((int64_t)b * C + ci) * T + ts] : 0.f;
+        hi[e] = f2bf(v);
+        lo[e] = f2bf(v - bf2f(hi[e]));
+    }
+    *reinterpret_cast<bf16x8*>(out + (int64_t)m * KP + k0) = hi;
+    *reinterpret_cast<bf16x8*>(out + plane + (int64_t)m * KP + k0) = lo;
+}
+int launch_im2col_latent(const float* x, int B, int C, int T, int taps, int pad, int KP, bf16_t* out, int64_t plane, hipStream_t st) {
+    if (KP % 8 || C > 32 || taps * 32 > KP) VB_FAIL(VB_E_INVALID, "im2col_latent: C=%d taps=%d KP=%d", C, taps, KP);
+    const int64_t n = (int64_t)B * T * (KP / 8);
+    hipLaunchKernelGGL(im2col_latent_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, B, C, T, taps, pad, KP, out, plane);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+__global__ void conv_w_to_gemm_kernel(const bf16_t* __restrict__ w3, int64_t w3_plane, int taps, int D, int KP, bf16_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (plane, co, k)
+    if (idx >= (int64_t)2 * D * KP) return;
+    const int k = (int)(idx % KP), co = (int)((idx / KP) % D), pl = (int)(idx / ((int64_t)KP * D));
+    const int tap = k >> 5, ci = k & 31;
+    out[idx] = tap < taps ? w3[pl * w3_plane + ((int64_t)tap * D + co) * 32 + ci] : f2bf(0.f);
+}
+int launch_conv_w_to_gemm(const bf16_t* w3, int64_t w3_plane, int taps, int D, int KP, bf16_t* out, hipStream_t st) {
+    const int64_t n = (int64_t)2 * D * KP;
+    hipLaunchKernelGGL(conv_w_to_gemm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w3, w3_plane, taps, D, KP, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+
 // element (row n = (branch*B + b)*T + t, e) of stream (seed, clip_base + b, nfe, branch, block, gate)
 __global__ void fill_gumbel_kernel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base,
                                    int nfe_base, const int* step, int block, int gate) {

@@ -37,6 +37,8 @@ static void tune_load() {
     t.w2_pair = env_int("VB_W2_PAIR", 1);
     t.qkv_p16_off = getenv("VB_QKV_P16_OFF") != nullptr;
     t.no_xcd_groups = getenv("VB_NO_XCD_GROUPS") != nullptr;
+    t.wide_resid = env_int("VB_WIDE_RESID", 1);
+    t.proj_in_conv = getenv("VB_PROJ_IN_CONV") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
@@ -176,6 +178,7 @@ static inline Planes wpl(const void* p, int64_t numel, int np) { return Planes{(
 // ------------------------------------------------------------------------------------------
 // layouts
 // ------------------------------------------------------------------------------------------
+#define PIN_KP 192      // K of proj_in as a GEMM: 5 taps x 32 (channels padded) = 160, padded to a multiple of 64
 struct CondL {
     float* ac; float* cemb;
     bf16_t* ky[VB_MAX_DEPTH]; bf16_t* vyt[VB_MAX_DEPTH]; bf16_t* kc[VB_MAX_DEPTH]; bf16_t* vct[VB_MAX_DEPTH];
@@ -183,6 +186,7 @@ struct CondL {
     // folded caption gate (see router_kernel<.., true>): per clip and block the caption keys with the MoE q-projection folded in
     // (planes [Beff][NS = L*heads][D], row = key*heads + head), the q-bias part of the scores and the gate-contracted values
     bf16_t* mf[VB_MAX_DEPTH]; float* cb[VB_MAX_DEPTH]; float* vw[VB_MAX_DEPTH]; int* clip_off; int NS; bool fold;
+    bf16_t* pin_w;       // proj_in weights as a GEMM operand: split planes [2][D][PIN_KP], k = tap * 32 + ci (conv_w_to_gemm_kernel)
     int64_t n_k, n_vt; int Lpad;
     size_t total;
 };
@@ -214,6 +218,7 @@ static CondL carve_cond(void* base, const vb_dit_config& c, int B, int nb, int T
         o.cb[i] = o.fold ? cv.take<float>((size_t)Beff * o.NS) : nullptr;
         o.vw[i] = o.fold ? cv.take<float>((size_t)Beff * o.NS * c.num_experts) : nullptr;
     }
+    o.pin_w = cv.take<bf16_t>((size_t)2 * D * PIN_KP);
     o.total = cv.off;
     return o;
 }
@@ -225,7 +230,7 @@ struct WsL {
     float *temb0, *temb, *mod_all, *hl, *h, *cq32, *mc, *ma, *y32, *g1, *g2, *g3, *v;
     bf16_t* modA;                                                   // A operand (planes) of the adaLN tabulation GEMM
     float *temb0_s, *temb_s, *hl_s, *mod_s; int64_t* row_step;     // per-sample tables of the conditioning vectors of every step
-    bf16_t *u, *q, *k, *vt, *a, *qm, *cqa, *Hs, *y, *Hf;
+    bf16_t *u, *q, *k, *vt, *a, *qm, *cqa, *Hs, *y, *Hf, *pin_a;
     int *ic, *ia, *group_off, *perm, *pair_off, *pair_pa;
     // precompute temporaries
     float *tA, *tB, *tC, *tD, *tE, *cap_pre, *cap32, *pooled, *pooled_ln;
@@ -271,6 +276,7 @@ static WsL carve_ws(void* base, const vb_dit_config& c, int B, int nb, int T, in
     o.ia = cv.take<int>(N);
     o.group_off = cv.take<int>(2 * E + 1);
     o.perm = cv.take<int>(2 * N + bucket_scratch_ints((int)N, E));
+    o.pin_a = cv.take<bf16_t>((size_t)2 * B * T * PIN_KP);
     o.pair_off = cv.take<int>(32);
     o.pair_pa = cv.take<int>(N);
     // precompute temporaries
@@ -393,6 +399,8 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
         }
     }
     VB_TRY(launch_iota_mul(cd.clip_off, Beff + 1, T, st));
+    if (w.proj_in_w3 && c.in_channels <= 32)
+        VB_TRY(launch_conv_w_to_gemm((const bf16_t*)w.proj_in_w3, (int64_t)5 * D * 32, 5, D, PIN_KP, cd.pin_w, st));
     return VB_OK;
 }
 
@@ -426,7 +434,19 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     }
 
     // ---- h = proj_in(x)^T + acoustic   (vocal2music_moe.py:395,415)
-    {
+    // As a GEMM (round 3): the k = 5 convolution over 20 channels is a K = 100 product per token - as a conv launch it was 1152 workgroups
+    // each staging 80 KB of weights for 60 MFMAs per wave (79 us per evaluation, 0.7 TB/s of output).  The latent windows are laid out as
+    // K-contiguous split planes (im2col, 6016 x 192 at 8 clips), multiplied with the re-laid conv weights in split precision (fp32-class,
+    // as before), + bias + acoustic embedding in the epilogue, and the row is written for BOTH CFG branches (they embed the same x).
+    if (w.proj_in_w3 && c.in_channels <= 32 && !vb_tune().proj_in_conv) {
+        const int BT = B * T;
+        VB_TRY(launch_im2col_latent(x, B, c.in_channels, T, 5, 2, PIN_KP, s.pin_a, (int64_t)BT * PIN_KP, st));
+        GemmArgs g;
+        g.A = s.pin_a; g.a_plane = (int64_t)BT * PIN_KP; g.lda = PIN_KP; g.B = cd.pin_w; g.b_plane = (int64_t)D * PIN_KP; g.ldb = PIN_KP;
+        g.M = BT; g.N = D; g.K = PIN_KP; g.nseg = 3; g.epi = EPI_F32; g.bias = w.proj_in_b; g.out32 = s.h; g.ldc32 = D;
+        g.add32 = cd.ac; g.dup_rows = nb == 2 ? BT : 0;
+        VB_TRY(launch_gemm(g, st));
+    } else {
         ConvArgs cv;
         cv.x = x; cv.x_bstride = (int64_t)c.in_channels * T; cv.Ci = c.in_channels; cv.T_in = T; cv.x_bmod = B;
         cv.w = w.proj_in_w; cv.bias = w.proj_in_b; cv.Co = D; cv.ksize = 5; cv.pad = 2;

@@ -39,6 +39,7 @@ struct GemmDev {
     const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
     const float* row_scale2; int scale_split;
     int grp_rows, grp_tiles;        // uniform groups (per-clip operands): rows per group, row tiles per group; 0 = off
+    const float* add32; int dup_rows;   // EPI_F32: + add32[m][n]; second copy of the row at m + dup_rows
     int ncc, rpx;                   // 128x128 kernel, wide N: column tiles are visited in chunks of ncc (0 = off) over the rpx row tiles of an XCD
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
@@ -105,6 +106,9 @@ __device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok
     e.a = make_float4(0.f, 0.f, 0.f, 0.f); e.b = e.a;
     if constexpr (EPI == EPI_PLANES || EPI == EPI_F32 || EPI == EPI_GELU_PLANES || EPI == EPI_HEADS_T || EPI == EPI_F32_CT) {
         if (p.bias) e.a = *reinterpret_cast<const float4*>(p.bias + g * p.bias_group_stride + n);
+        if constexpr (EPI == EPI_F32) {
+            if (p.add32) e.b = *reinterpret_cast<const float4*>(p.add32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n);
+        }
     } else if constexpr (EPI == EPI_RESID_GATE) {
         const int col = g * p.c_noff_group + n;
         e.a = *reinterpret_cast<const float4*>(p.out32 + (int64_t)m * p.ldc32 + col);
@@ -138,7 +142,9 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f));
         store4p(p.out, p.out_plane, p.out_np, (int64_t)m * p.ldc + g * p.c_noff_group + n, v);
     } else if constexpr (EPI == EPI_F32) {
+        if (p.add32) { v[0] += e.b.x; v[1] += e.b.y; v[2] += e.b.z; v[3] += e.b.w; }
         *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.dup_rows > 0) *reinterpret_cast<float4*>(p.out32 + (int64_t)(m + p.dup_rows) * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_F32_CT) {
         const int b = fdiv(m, p.rT), t = m - b * p.T;
 #pragma unroll
@@ -916,6 +922,138 @@ int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st) {
     }
     VB_CHECK_LAUNCH();
     return VB_OK;
+}
+
+// ---- 128 x 192 tiles, two workgroups per CU, gated-residual epilogue in the P16 layout (attention out-proj at >= 8 clips) ----------
+// 12032 x 768 makes 564 tiles of 128 x 128 (1.1 rounds of the 512 two-per-CU slots, priced as 2) and 252 of 192 x 192 on the one-per-CU
+// kernel, whose tiles all reach their read-modify-write epilogue together (39.8 us, 12.4 % MFMA-busy).  128 x 192 tiles make 376
+// workgroups = ONE round at two per CU (80 KB of LDS each): the co-resident workgroup overlaps the other's epilogue, and the P16 layout
+// gives a lane 16 consecutive fp32 columns (four 16-byte loads of h, four of the gate row, four stores).  Same k order and epilogue
+// arithmetic as every other tile configuration (test_gemm_tile_configurations_round_alike).
+template <int TN>
+__global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_bf16_wide_resid_kernel(const GemmDev p) {
+    constexpr int BKT = 64, NST = 2, CH = 8, RS = 8;
+    constexpr int BNP = 64 * TN;
+    constexpr int SPA = 4, SPB = BNP / 32;
+    constexpr int ABYTES = BM * BKT * 2, BBYTES = BNP * BKT * 2, STAGE = ABYTES + BBYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int L = blockIdx.x, nN = p.n_tiles;
+    const int jx = L >> 3;
+    const int tile_n = jx % nN;
+    const int row0 = ((jx / nN) * 8 + (L & 7)) * BM, rows_end = p.M;
+    if (row0 >= rows_end) return;
+    const int n0 = tile_n * BNP;
+    const int KT = p.K / BKT;
+    const int total = KT * p.nseg;
+
+    const bf16_t* asrc[SPA]; const bf16_t* bsrc[SPB];
+#pragma unroll
+    for (int i = 0; i < SPA; ++i) {
+        const int r = RS * (wave * SPA + i) + lane / CH;
+        const int c = (lane % CH) ^ ((r >> 1) & 7);
+        int slot = row0 + r;
+        if (slot >= rows_end) slot = row0;
+        asrc[i] = p.A + (int64_t)slot * p.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < SPB; ++i) {
+        const int r = RS * (wave * SPB + i) + lane / CH;
+        const int c = (lane % CH) ^ ((r >> 1) & 7);
+        int nrow = n0 + p16_src_row(r);
+        if (nrow >= p.N) nrow = 0;
+        bsrc[i] = p.B + (int64_t)nrow * p.ldb + c * 8;
+    }
+    auto issue = [&](int t) {
+        const int st = t % NST;
+        const int seg = t / KT;
+        const int k0 = (t - seg * KT) * BKT;
+        const int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
+        const int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+        unsigned char* sa = lds + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < SPA; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(asrc[i] + ao), (lds_ptr_t)(sa + (wave * SPA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < SPB; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bsrc[i] + bo), (lds_ptr_t)(sa + ABYTES + (wave * SPB + i) * 1024), 16, 0, 0);
+    };
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    issue(0);
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < total; ++t) {
+        const int st = t % NST;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < total) issue(t + 1);
+        const unsigned char* As = lds + st * STAGE;
+        const unsigned char* Bs = As + ABYTES;
+        bf16x8 af[2][2], bf[2][TN];
+        auto fload = [&](int ks, int slot) {
+            const int c = ks * 2 + fk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[slot][i] = *reinterpret_cast<const bf16x8*>(As + lds_off_t<BKT>(wr * 64 + i * 32 + frow, c));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const bf16x8*>(Bs + lds_off_t<BKT>(wc * 32 * TN + j * 32 + frow, c));
+        };
+        fload(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < BKT / 16) fload(ks + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // epilogue (EPI_RESID_GATE): out32[m][n..n+15] = fmaf(gate[clip(m)][n..], v, out32[m][n..]); loads of a row slab first, then the stores
+    {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = row0 + wr * 64 + i * 32 + frow;
+            if (m >= rows_end) continue;
+            float* hrow = p.out32 + (int64_t)m * p.ldc32;
+            const float* grow = p.gate + (int64_t)fdiv(m, p.rT) * p.gate_ld;
+            float4 hv[TN][4], gv[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * 32 * TN + j * 32 + fk * 16;
+                if (n < p.N) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        hv[j][q] = *reinterpret_cast<const float4*>(hrow + n + 4 * q);
+                        gv[j][q] = *reinterpret_cast<const float4*>(grow + n + 4 * q);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wc * 32 * TN + j * 32 + fk * 16;
+                if (n >= p.N) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = fmaf(gv[j][q].x, acc[i][j][4 * q + 0], hv[j][q].x); o.y = fmaf(gv[j][q].y, acc[i][j][4 * q + 1], hv[j][q].y);
+                    o.z = fmaf(gv[j][q].z, acc[i][j][4 * q + 2], hv[j][q].z); o.w = fmaf(gv[j][q].w, acc[i][j][4 * q + 3], hv[j][q].w);
+                    *reinterpret_cast<float4*>(hrow + n + 4 * q) = o;
+                }
+            }
+        }
+    }
 }
 
 // ---- variant 3: big block tiles, one workgroup per CU --------------------------------------------------------------
@@ -1878,6 +2016,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.out = a.out.p; d.out_plane = a.out.plane; d.out_np = a.out.np; d.ldc = a.ldc;
     d.out32 = a.out32; d.ldc32 = a.ldc32; d.gate = a.gate; d.gate_ld = a.gate_ld; d.T = a.T > 0 ? a.T : 1;
     d.rows_out = a.rows_out; d.row_scale = a.row_scale; d.y32_in = a.y32_in; d.row_scale2 = a.row_scale2; d.scale_split = a.scale_split;
+    d.add32 = a.add32; d.dup_rows = a.dup_rows;
     d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
     d.qkv_np = a.q.np; d.rope_cos = a.rope_cos; d.rope_sin = a.rope_sin; d.H = a.H; d.hd = a.hd > 0 ? a.hd : 1;
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
@@ -1903,8 +2042,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     int cfg = 0;
     if (a.K % 64 == 0) {
         const int forced = vb_tune().gemm_tile;
-        if (forced >= 0) cfg = forced == 22 ? 0 : forced;
-        else {
+        if (forced >= 0) {
+            cfg = forced == 22 ? 0 : forced;
+            if (cfg == 23 && !(a.epi == EPI_RESID_GATE && !a.group_off && a.ngroups <= 1 && a.N % 192 == 0)) cfg = 0;    // 23 serves the plain gated-residual GEMM
+        } else {
             // measured (tools/gemm_tilecfg.py): the 192x192 kernel wins when its tiles fit one round of the 256 CUs
             // (12032 x 768: 252 tiles); with several rounds per CU the 128x128 kernel (two co-resident workgroups
             // overlapping each other's epilogue) is as fast or faster.
@@ -1912,7 +2053,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             const int64_t rt = a.group_off ? (cdiv(a.M, 192) + a.ngroups) : cdiv(a.M, 192);
             const int64_t t33 = rt * cdiv(a.N, 192) * gz;
             const int64_t t22 = (a.group_off ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
-            if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
+            const int64_t t23 = (int64_t)cdiv(a.M, BM) * (a.N / 192);
+            if (a.epi == EPI_RESID_GATE && !a.group_off && gz == 1 && a.N % 192 == 0 && t22 > 512 && t23 <= 512 && vb_tune().wide_resid) cfg = 23;
+            else if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
             // small problems (one or two clips): 128x128 tiles leave most CUs idle and a tile's 12 k-iterations are pure DMA latency;
             // 64x64 tiles (three workgroups per CU) make 4x the tiles.  VB_GEMM_SMALL=0 keeps the 128x128 kernel, 21 takes 128x64.
             else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles) cfg = vb_tune().gemm_small;
@@ -1940,6 +2083,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
     }
 #endif
+    if (cfg == 23) {     // 128 x 192, two per CU, gated-residual epilogue (gemm_bf16_wide_resid_kernel)
+        if (a.epi != EPI_RESID_GATE || a.group_off || a.N % 192 || a.K % 64) VB_FAIL(VB_E_INVALID, "gemm: tile 23 serves the plain gated-residual GEMM only");
+        d.n_tiles = a.N / 192;
+        hipLaunchKernelGGL(gemm_bf16_wide_resid_kernel<3>, dim3(d.n_tiles * ((cdiv(a.M, BM) + 7) / 8 * 8)), dim3(NTHREADS), 0, st, d);
+        VB_CHECK_LAUNCH();
+        return VB_OK;
+    }
     const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);

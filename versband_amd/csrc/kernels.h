@@ -41,6 +41,9 @@ struct GemmArgs {
     // EPI_SWIGLU only: per-row gate weight folded into the hidden value BEFORE its bf16 rounding (rows < scale_split take
     // row_scale[a_rows[m]], the others row_scale2[a_rows[m]]): lets the routed w2 product run as one plain K-concatenated GEMM
     const float* row_scale2 = nullptr; int scale_split = 0;
+    // EPI_F32 only: out32[m][n] = v + bias + add32[m][n] (same leading dimension), written to row m AND, when dup_rows > 0, to row
+    // m + dup_rows (both CFG branches start from the same embedded latent)
+    const float* add32 = nullptr; int dup_rows = 0;
     Planes q = {nullptr, 0, 1}, k = {nullptr, 0, 1}, vt = {nullptr, 0, 1};
     const float* rope_cos = nullptr; const float* rope_sin = nullptr;
     int H = 1, hd = 1, Tpad = 0, D = 0;
@@ -197,6 +200,9 @@ int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this man
 int launch_gate_fold(Planes kc, Planes vct, const float* bq_s, const float* wcg, int Beff, int L, int Lpad, int Hh, int hd, int E,
                      float* cbias, float* vw, hipStream_t st);
 int launch_iota_mul(int* out, int n, int mul, hipStream_t st);
+// proj_in as a GEMM (elementwise.hip): latent windows as K-contiguous split planes, conv weights re-laid as a GEMM operand
+int launch_im2col_latent(const float* x, int B, int C, int T, int taps, int pad, int KP, bf16_t* out, int64_t plane, hipStream_t st);
+int launch_conv_w_to_gemm(const bf16_t* w3, int64_t w3_plane, int taps, int D, int KP, bf16_t* out, hipStream_t st);
 int launch_router_top1(const float* logits, const float* gumbel, int N, int E, int* idx, hipStream_t st);
 int launch_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe_base,
                        const int* step, int block, int gate, hipStream_t st);
