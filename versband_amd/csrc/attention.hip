@@ -16,7 +16,10 @@
 // (Round 3, measured and dropped: the cross keys visited twice - statistics pass in front of the self pass, accumulate pass behind
 //  it - removes the 48-KB stash (LDS 74 -> 26 KB), but at two waves per SIMD the kernel runs 64.4 us against 61.7 with the stash, and
 //  three waves per SIMD need <= 168 registers where the kernel holds 254 (o 48 + s 32 + q 24 + K/V prefetch 24 + fragments): forced,
-//  the compiler spills 41.)
+//  the compiler spills 41.  Also measured and dropped: the K tile's rows permuted like the V^T tile's so that a lane's 8 probabilities
+//  of one P.V MFMA are 8 consecutive keys and the V^T fragment is ONE 16-byte LDS read (144-byte rows) instead of two 8-byte ones:
+//  58.0 us against 55.3 on like boxes - and a whole-uint4 LDS store of the prefetch register array sent that array through scratch
+//  memory (108 us) until it was written component-wise.)
 #include <stdlib.h>
 
 #include "kernels.h"
