@@ -437,6 +437,30 @@ def test_proj_in_as_gemm_matches_the_conv_launch(engines, monkeypatch, prec, B, 
     assert int((r1 != r2).sum()) <= (4 if prec == "bf16" else 0)
 
 
+@pytest.mark.parametrize("B,T", [(2, 752), (3, 100)])
+def test_vae_wide_convs_as_gemm_match_the_conv_kernel(ctx, monkeypatch, B, T):
+    """The VAE's wide layers (>= 384 output channels, pre-activated transposed planes as input) run as tap-by-tap GEMMs on the DMA-fed
+    128 x 128 kernel (split precision, bias + residual in a channel-major epilogue); VB_CONV_GEMM_OFF=1 restores the conv kernel.
+    Both are bf16x3 evaluations of the same sums in another order: decoder outputs agree to fp32 rounding noise (ragged tiles: T = 100)."""
+    from versband_amd.engine import build_vae_decoder
+    sdv = synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), SEED + 1)
+    vae = build_vae_decoder(ctx, sdv)
+    z = torch.from_numpy(prng.normal(77, B * 20 * T)).float().reshape(B, 20, T)
+    m1 = vae.run(z).clone()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("VB_CONV_GEMM_OFF", "1")
+    L.load().vb_tune_reload()
+    m2 = vae.run(z).clone()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("VB_CONV_GEMM_OFF")
+    L.load().vb_tune_reload()
+    err = rel_l2(m1, m2)
+    print(f"VAE decode, wide convs as GEMM vs conv kernel: rel_l2 {err:.3e}")
+    assert torch.isfinite(m1).all() and err < 2e-5, describe("VAE wide convs as GEMM", m1, m2)
+    ref = ref_cpu.vae_decode(sdv, z)
+    assert rel_l2(m1, ref) < 2e-4, describe("VAE decode vs oracle", m1, ref)
+
+
 @pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_NO_XCD_GROUPS"])
 @pytest.mark.parametrize("prec,B,T", [("bf16", 4, 752), ("split", 3, 700)])
 def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T, knob):

@@ -571,6 +571,23 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if ((d.ntaps - 1) * d.dil > XHALO) VB_FAIL(VB_E_INVALID, "conv1d: halo %d exceeds %d", (d.ntaps - 1) * d.dil, XHALO);
     if (a.out_transposed && (a.Co % 4)) VB_FAIL(VB_E_INVALID, "conv1d: transposed output needs Co%%4==0");
     if ((a.in_act == ACT_GN_SWISH || a.in_act == ACT_GN) && (a.Ci % a.gn_groups)) VB_FAIL(VB_E_INVALID, "conv1d: Ci %% groups");
+    // Wide layers over pre-activated transposed planes ARE GEMMs (rows = clip x time, K = taps x Ci, both operands K-contiguous
+    // already): the DMA-fed 128 x 128 GEMM kernel walks K tap by tap (GemmArgs::conv_*), three bf16 passes for the split precision,
+    // bias + residual in a channel-major epilogue.  Measured on these shapes (tools/conv_as_gemm_calib.py): 750-840 TFLOP/s of bf16
+    // MFMA work against ~385 of this file's kernel, which stages weights through registers and synchronises per (tap, 32 channels).
+    if (a.xt && a.wp && a.Co >= 384 && a.Ci % 64 == 0 && a.Ci_pad == a.Ci && a.Co % 4 == 0 && d.phases == 1 && !a.wp_bstride && !a.w_bstride &&
+        a.alpha == 1.f && a.beta == 0.f && a.acc_scale == 1.f && a.out_act == ACT_NONE && !a.out_transposed && !a.add &&
+        a.out_bstride == (int64_t)a.Co * a.T_out && (!a.res || a.res_bstride == a.out_bstride) &&
+        a.T_out == (a.upsample2 ? 2 * a.T_in : a.T_in) && !vb_tune().conv_gemm_off) {
+        GemmArgs g;
+        g.A = a.xt; g.a_plane = d.xt_plane; g.lda = a.Ci; g.B = a.wp; g.b_plane = a.wp_plane; g.ldb = a.Ci_pad;
+        g.M = a.B * a.T_out; g.N = a.Co; g.K = d.ntaps * a.Ci; g.nseg = 3; g.ngroups = a.B;
+        g.group_off = reinterpret_cast<const int*>(a.xt);        // uniform groups: only its non-nullness is looked at (group_rows > 0)
+        g.group_rows = a.T_out; g.T = a.T_out; g.epi = EPI_F32_CT; g.bias = a.bias; g.out32 = a.out; g.res32 = a.res;
+        g.conv_ci = a.Ci; g.conv_dil = d.dil; g.conv_agrp = d.xt_Tp; g.conv_arow0 = XT_HEAD - a.pad; g.conv_btap = (int64_t)a.Co * a.Ci_pad;
+        g.prof_class = 2;
+        return launch_gemm(g, st);
+    }
     const double taps_eff = a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize;
     ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * taps_eff,
                    4.0 * a.B * ((double)a.Ci * a.T_in * (a.xt ? 1.0 : 1.0) + (double)a.Co * a.T_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.beta != 0.f ? 1.0 : 0.0)))

@@ -39,6 +39,7 @@ static void tune_load() {
     t.no_xcd_groups = getenv("VB_NO_XCD_GROUPS") != nullptr;
     t.wide_resid = env_int("VB_WIDE_RESID", 1);
     t.proj_in_conv = getenv("VB_PROJ_IN_CONV") != nullptr;
+    t.conv_gemm_off = getenv("VB_CONV_GEMM_OFF") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
@@ -444,7 +445,7 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         GemmArgs g;
         g.A = s.pin_a; g.a_plane = (int64_t)BT * PIN_KP; g.lda = PIN_KP; g.B = cd.pin_w; g.b_plane = (int64_t)D * PIN_KP; g.ldb = PIN_KP;
         g.M = BT; g.N = D; g.K = PIN_KP; g.nseg = 3; g.epi = EPI_F32; g.bias = w.proj_in_b; g.out32 = s.h; g.ldc32 = D;
-        g.add32 = cd.ac; g.dup_rows = nb == 2 ? BT : 0;
+        g.add32 = cd.ac; g.dup_rows = nb == 2 ? BT : 0; g.prof_class = 2;       // split-precision convolution work: counted with the conv class
         VB_TRY(launch_gemm(g, st));
     } else {
         ConvArgs cv;

@@ -40,6 +40,7 @@ struct GemmDev {
     const float* row_scale2; int scale_split;
     int grp_rows, grp_tiles;        // uniform groups (per-clip operands): rows per group, row tiles per group; 0 = off
     const float* add32; int dup_rows;   // EPI_F32: + add32[m][n]; second copy of the row at m + dup_rows
+    int conv_ci, conv_ktap, conv_dil, conv_agrp, conv_arow0; int64_t conv_btap; const float* res32;   // conv-as-GEMM mode (EPI_F32_CT), see GemmArgs
     int ncc, rpx;                   // 128x128 kernel, wide N: column tiles are visited in chunks of ncc (0 = off) over the rpx row tiles of an XCD
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
@@ -109,6 +110,13 @@ __device__ __forceinline__ void epi_load(const GemmDev& p, int g, int m, int tok
         if constexpr (EPI == EPI_F32) {
             if (p.add32) e.b = *reinterpret_cast<const float4*>(p.add32 + (int64_t)m * p.ldc32 + g * p.c_noff_group + n);
         }
+        if constexpr (EPI == EPI_F32_CT) {
+            if (p.res32) {
+                const int b = fdiv(m, p.rT), t = m - b * p.T;
+                const float* rp = p.res32 + ((int64_t)b * p.N + n) * p.T + t;
+                e.b = make_float4(rp[0], rp[p.T], rp[2 * (int64_t)p.T], rp[3 * (int64_t)p.T]);
+            }
+        }
     } else if constexpr (EPI == EPI_RESID_GATE) {
         const int col = g * p.c_noff_group + n;
         e.a = *reinterpret_cast<const float4*>(p.out32 + (int64_t)m * p.ldc32 + col);
@@ -147,6 +155,7 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         if (p.dup_rows > 0) *reinterpret_cast<float4*>(p.out32 + (int64_t)(m + p.dup_rows) * p.ldc32 + g * p.c_noff_group + n) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (EPI == EPI_F32_CT) {
         const int b = fdiv(m, p.rT), t = m - b * p.T;
+        if (p.res32) { v[0] += e.b.x; v[1] += e.b.y; v[2] += e.b.z; v[3] += e.b.w; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) p.out32[((int64_t)b * p.N + n + i) * p.T + t] = v[i];
     } else if constexpr (EPI == EPI_RESID_GATE) {
@@ -654,7 +663,10 @@ gemm_bf16_glds_kernel(const GemmDev p) {
         const int c = (BKT == 64) ? (cs ^ ((r >> 1) & 7)) : (cs ^ ((r >> 2) & 3));
         int slot = row0 + r;
         if (slot >= rows_end) slot = row0;
-        const int arow = p.a_rows ? p.a_rows[slot] : slot;
+        int arow = p.a_rows ? p.a_rows[slot] : slot;
+        if constexpr (EPI == EPI_F32_CT) {
+            if (p.conv_ktap > 0) arow = g * p.conv_agrp + p.conv_arow0 + (slot - g * p.grp_rows);      // clip g's padded plane image, row of tap 0
+        }
         asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
         int nrow = n0 + (P16 ? p16_src_row(r) : r);
         if (nrow >= p.N) nrow = 0;
@@ -664,8 +676,15 @@ gemm_bf16_glds_kernel(const GemmDev p) {
         const int st = t % NST;
         const int seg = t / KT;
         const int k0 = (t - seg * KT) * BKT;
-        const int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
-        const int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+        int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
+        int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+        if constexpr (EPI == EPI_F32_CT && BKT == 64) {
+            if (p.conv_ktap > 0) {       // conv mode: k-tile -> (tap, channel chunk); tap j reads the rows j * dil below tap 0's
+                const int kt = t - seg * KT, tap = kt / p.conv_ktap, c0 = (kt - tap * p.conv_ktap) * BKT;
+                ao = (seg == 1 ? p.a_plane : 0) + (int64_t)tap * p.conv_dil * p.lda + c0;
+                bo = (seg == 2 ? p.b_plane : 0) + (int64_t)tap * p.conv_btap + c0;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < SPW; ++i) {
             const int s = wave * SPW + i;
@@ -744,6 +763,8 @@ gemm_bf16_glds_kernel(const GemmDev p) {
             for (int j = 0; j < 2; ++j) sink += acc[i][j][0] + acc[i][j][9];
         if (sink == 12345.678f) p.out32[0] = sink;
     } else {
+        // (conv-as-GEMM, EPI_F32_CT: a channel-major epilogue staged through LDS - 16-byte residual loads and stores - measured the same
+        //  as the direct 4-byte one, 234 vs 230 us per VAE layer: these launches are mainloop-bound at K = 1920 .. 7680; not kept)
         if constexpr (P16 && EPI == EPI_QKV_ROPE) wave_epilogue_qkv_p16<2, 2>(p, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
         else if constexpr (P16 && EPI == EPI_SWIGLU) wave_epilogue_swiglu_p16<2, 2>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
         else if constexpr (STAGED_EPI(EPI)) staged_epilogue<EPI, 2, 2>(p, g, acc, reinterpret_cast<float*>(lds), row0, rows_end, n0, tid, wr, wc, frow, fk);
@@ -2017,6 +2038,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.out32 = a.out32; d.ldc32 = a.ldc32; d.gate = a.gate; d.gate_ld = a.gate_ld; d.T = a.T > 0 ? a.T : 1;
     d.rows_out = a.rows_out; d.row_scale = a.row_scale; d.y32_in = a.y32_in; d.row_scale2 = a.row_scale2; d.scale_split = a.scale_split;
     d.add32 = a.add32; d.dup_rows = a.dup_rows;
+    d.conv_ci = a.conv_ci; d.conv_ktap = 0; d.conv_dil = a.conv_dil; d.conv_agrp = a.conv_agrp; d.conv_arow0 = a.conv_arow0; d.conv_btap = a.conv_btap;
+    d.res32 = a.res32;
+    if (a.conv_ci > 0) {
+        if (a.epi != EPI_F32_CT || !a.group_off || a.group_rows <= 0 || a.conv_ci % 64 || a.K % a.conv_ci || a.a_rows || a.group_rows != (a.T > 0 ? a.T : 1))
+            VB_FAIL(VB_E_INVALID, "gemm: conv mode needs EPI_F32_CT, uniform groups of T rows, Ci %% 64 == 0");
+        d.conv_ktap = a.conv_ci / 64;
+    }
     d.q = a.q.p; d.q_plane = a.q.plane; d.k = a.k.p; d.k_plane = a.k.plane; d.vt = a.vt.p; d.vt_plane = a.vt.plane;
     d.qkv_np = a.q.np; d.rope_cos = a.rope_cos; d.rope_sin = a.rope_sin; d.H = a.H; d.hd = a.hd > 0 ? a.hd : 1;
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
@@ -2034,7 +2062,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         case EPI_QKV_ROPE: ob_ = 2.0 * MN_ * a.q.np; break;
         default: ob_ = 2.0 * MN_ * a.out.np; break;
     }
-    ProfScope prof(0, 2.0 * MN_ * a.K,
+    ProfScope prof(a.prof_class, 2.0 * MN_ * a.K,
                    2.0 * npl_ * ((double)a.M * a.K * (a.a_koff_group ? gz_ : 1.0) + (double)a.N * a.K * (a.ngroups > 1 ? a.ngroups : 1)) + ob_, st);
     // tile configuration: 0 = 128x128 (two workgroups per CU), else (TM, TN) of the big-tile kernel (one per CU).  The
     // big tiles are taken when K allows the DMA ring; among them the one that wastes the fewest tile-slots of the last
@@ -2083,6 +2111,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
     }
 #endif
+    if (a.conv_ci > 0) cfg = 0;
     if (cfg == 23) {     // 128 x 192, two per CU, gated-residual epilogue (gemm_bf16_wide_resid_kernel)
         if (a.epi != EPI_RESID_GATE || a.group_off || a.N % 192 || a.K % 64) VB_FAIL(VB_E_INVALID, "gemm: tile 23 serves the plain gated-residual GEMM only");
         d.n_tiles = a.N / 192;
@@ -2094,7 +2123,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
     d.grp_rows = 0; d.grp_tiles = 0;
-    if (!cfg && a.group_off && a.group_rows > 0 && a.K % 32 == 0 && !vb_tune().no_xcd_groups) {      // 128 x 128 DMA kernels only
+    if (a.conv_ci > 0 && (cfg || a.K % 64)) VB_FAIL(VB_E_INVALID, "gemm: conv mode runs on the 128 x 128 DMA kernel (K %% 64 == 0)");
+    if (!cfg && a.group_off && a.group_rows > 0 && a.K % 32 == 0 && (!vb_tune().no_xcd_groups || a.conv_ci > 0)) {      // 128 x 128 DMA kernels only
         d.grp_rows = a.group_rows; d.grp_tiles = cdiv(a.group_rows, BM);
         mt = cdiv(a.ngroups, 8) * 8 * d.grp_tiles;
     }

@@ -44,6 +44,11 @@ struct GemmArgs {
     // EPI_F32 only: out32[m][n] = v + bias + add32[m][n] (same leading dimension), written to row m AND, when dup_rows > 0, to row
     // m + dup_rows (both CFG branches start from the same embedded latent)
     const float* add32 = nullptr; int dup_rows = 0;
+    // Conv1d as a GEMM over pre-activated transposed planes (EPI_F32_CT with group_rows = T_out): K = taps * conv_ci walks tap by tap -
+    // the A rows of tap j are the rows of tap 0 shifted by j * conv_dil, its B operand sits conv_btap elements behind tap j-1's; group g
+    // (a clip) starts at A row g * conv_agrp + conv_arow0; res32 (same [b][n][t] layout as the output) is added in the epilogue.
+    int conv_ci = 0, conv_dil = 1, conv_agrp = 0, conv_arow0 = 0; int64_t conv_btap = 0; const float* res32 = nullptr;
+    int prof_class = 0;               // kernel class of the HIP-event profiler this launch is counted under (2 = split-bf16 convolution work)
     Planes q = {nullptr, 0, 1}, k = {nullptr, 0, 1}, vt = {nullptr, 0, 1};
     const float* rope_cos = nullptr; const float* rope_sin = nullptr;
     int H = 1, hd = 1, Tpad = 0, D = 0;
