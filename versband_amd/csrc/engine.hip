@@ -28,7 +28,7 @@ static void tune_load() {
     // product knobs: result-preserving selections the tests flip to compare both forms, plus VB_ATTN_DEFER / VB_NO_GRAPH
     t.router_tpw = env_int("VB_ROUTER_TPW", 0);
     if (const char* v = getenv("VB_ATTN_DEFER")) t.attn_defer_thr = (float)atof(v);     // log2 units; 0 = exact running maximum
-    t.gemm_small = env_int("VB_GEMM_SMALL", 11); t.gemm_small_tiles = env_int("VB_GEMM_SMALL_TILES", 300);
+    t.gemm_small = env_int("VB_GEMM_SMALL", 11); t.gemm_small_tiles = env_int("VB_GEMM_SMALL_TILES", 200);
     t.gemm_tile = env_int("VB_GEMM_TILE", -1);
     t.conv_cfg = env_int("VB_CONV_CFG", 0);
     t.conv_direct_epi = getenv("VB_CONV_DIRECT_EPI") != nullptr;

@@ -951,6 +951,12 @@ int launch_moe_w2_pair(const MoeW2PairArgs& a, hipStream_t st) {
 // workgroups = ONE round at two per CU (80 KB of LDS each): the co-resident workgroup overlaps the other's epilogue, and the P16 layout
 // gives a lane 16 consecutive fp32 columns (four 16-byte loads of h, four of the gate row, four stores).  Same k order and epilogue
 // arithmetic as every other tile configuration (test_gemm_tile_configurations_round_alike).
+// (Round 3, built, measured and removed - verdict item 1c: the Band-MoE input RMSNorm fused into this launch by "last arriver": every
+//  workgroup publishes its stores with an agent-scope release, bumps its row panel's counter, and the workgroup that lands the panel's
+//  last column tile normalises the 128 rows.  Bit-identical to the separate launch, no spinning, no placement assumed - and the
+//  agent-scope release is a buffer_wbl2 per workgroup: 36 -> 202 us per launch (1272 -> 1155 mel-s/s).  Dropping the release would
+//  lean on all column tiles of a panel sharing one XCD's L2, which the programming model does not promise.  The tail's registers also
+//  slowed the un-fused path of the same kernel, 36 -> 55 us.)
 template <int TN>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_bf16_wide_resid_kernel(const GemmDev p) {
     constexpr int BKT = 64, NST = 2, CH = 8, RS = 8;
@@ -2086,7 +2092,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             else if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
             // small problems (one or two clips): 128x128 tiles leave most CUs idle and a tile's 12 k-iterations are pure DMA latency;
             // 64x64 tiles (three workgroups per CU) make 4x the tiles.  VB_GEMM_SMALL=0 keeps the 128x128 kernel, 21 takes 128x64.
-            else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles) cfg = vb_tune().gemm_small;
+            // (threshold 200 tiles since round 3: at 4 clips x 2 branches - one sub-batch of the two-stream configuration, 282 tiles - the
+            //  128 x 128 kernel is ahead when another stream shares the GPU: 1287 vs 1280 mel-s/s over three interleaved runs; per-clip
+            //  grouped launches with >= 8 clips keep the 128 x 128 kernel for its XCD-affine tile order)
+            else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles && !(a.group_rows > 0 && a.ngroups >= 8 && !vb_tune().no_xcd_groups))
+                cfg = vb_tune().gemm_small;
         }
     }
 #ifdef VB_EXPERIMENTS
