@@ -410,11 +410,14 @@ def test_single_launch_routed_w2_matches_two_launch_path(engines, sds, monkeypat
             assert e1 < 5e-3 and e1 < 1.5 * e2 + 1e-4
 
 
+@pytest.mark.parametrize("knob", ["VB_PROJ_IN_CONV", "VB_FINAL_GEMM"])
 @pytest.mark.parametrize("prec,B,T,nb", [("bf16", 2, 752, 2), ("split", 3, 700, 2), ("split", 2, 333, 1)])
-def test_proj_in_as_gemm_matches_the_conv_launch(engines, monkeypatch, prec, B, T, nb):
+def test_proj_in_as_gemm_matches_the_conv_launch(engines, monkeypatch, prec, B, T, nb, knob):
     """proj_in (Conv1d 20 -> 768, k = 5) runs as im2col + split-precision GEMM with the bias / acoustic add in the epilogue and the row
     written for both CFG branches; VB_PROJ_IN_CONV=1 restores the conv launch.  Both are fp32-class evaluations of the same 100-term
-    sums in another order: the DiT output agrees to fp32 rounding noise and the routes are identical (conditional-only batches too)."""
+    sums in another order: the DiT output agrees to fp32 rounding noise and the routes are identical (conditional-only batches too).
+    Same for the FinalLayer: one wave per token row (LayerNorm + modulate in registers, exact-fp32 768 x 20 projection against LDS-resident
+    weights) against the split-planes kernel + MFMA GEMM it replaced (VB_FINAL_GEMM=1)."""
     eng = engines[(4, prec)]
     Lc = 80
     inp = clip_batch(B, T, Lc)
@@ -424,14 +427,14 @@ def test_proj_in_as_gemm_matches_the_conv_launch(engines, monkeypatch, prec, B, 
     v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=5, return_routes=True)
     torch.cuda.synchronize()
     v1, r1 = v1.clone(), r1.clone()
-    monkeypatch.setenv("VB_PROJ_IN_CONV", "1")
+    monkeypatch.setenv(knob, "1")
     L.load().vb_tune_reload()
     v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=5, return_routes=True)
     torch.cuda.synchronize()
-    monkeypatch.delenv("VB_PROJ_IN_CONV")
+    monkeypatch.delenv(knob)
     L.load().vb_tune_reload()
     err = rel_l2(v1, v2)
-    print(f"proj_in GEMM vs conv ({prec}): rel_l2 {err:.3e}, route flips {int((r1 != r2).sum())}")
+    print(f"{knob} off vs on ({prec}): rel_l2 {err:.3e}, route flips {int((r1 != r2).sum())}")
     assert torch.isfinite(v1).all()
     assert err < (2e-3 if prec == "bf16" else 2e-5), describe("proj_in as GEMM vs conv launch", v1, v2)
     assert int((r1 != r2).sum()) <= (4 if prec == "bf16" else 0)

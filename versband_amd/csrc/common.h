@@ -82,7 +82,7 @@ struct VbTune {
     int w2_pair = 1;
     bool qkv_p16_off = false, no_xcd_groups = false;
     int wide_resid = 1;
-    bool proj_in_conv = false, conv_gemm_off = false;
+    bool proj_in_conv = false, conv_gemm_off = false, final_gemm = false;
 };
 const VbTune& vb_tune();
 unsigned vb_tune_generation();      // bumped by vb_tune_reload(): anything that bakes knob-dependent kernel choices in (captured graphs) keys on it

@@ -40,6 +40,7 @@ static void tune_load() {
     t.wide_resid = env_int("VB_WIDE_RESID", 1);
     t.proj_in_conv = getenv("VB_PROJ_IN_CONV") != nullptr;
     t.conv_gemm_off = getenv("VB_CONV_GEMM_OFF") != nullptr;
+    t.final_gemm = getenv("VB_FINAL_GEMM") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
@@ -539,9 +540,10 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
                              s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st,
                              fold ? s.y32 : nullptr, cd.NS, c.heads));
         }
-        // routed w2 as ONE launch over (caption, acoustic) pair buckets: bf16 mode, E*E <= 16 groups, and enough tokens that the
-        // pair tiles' padding (<= one 128-row tile per pair) stays small; otherwise the two grouped w2 launches (bit-identical)
-        const bool w2_pair = np == 1 && E * E <= 16 && H % 64 == 0 && vb_tune().w2_pair && N >= 256 * E * E;
+        // routed w2 as ONE launch over (caption, acoustic) pair buckets: bf16 mode, E*E <= 16 groups; otherwise the two grouped w2 launches
+        // (at EVERY batch size: the pair form and the two-launch form round differently - the gate weight rides in the bf16 hidden rows -
+        //  and a clip's bits must not depend on the batch it rides in)
+        const bool w2_pair = np == 1 && E * E <= 16 && H % 64 == 0 && D % 16 == 0 && vb_tune().w2_pair;
         VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st, w2_pair ? s.pair_off : nullptr, s.pair_pa));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -597,7 +599,10 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     }
     // ---- FinalLayer (vocal2music_moe.py:287-291) -> v [Beff][C][T]
     const float* modf = mod_all + (size_t)c.depth * 6 * D;
-    if (w.final_wp && c.in_channels % 4 == 0 && (int64_t)2 * N * H >= ND) {
+    if (w.final_w && final_layer_fused_ok(D, c.in_channels) && !vb_tune().final_gemm) {
+        // one wave per token row: LayerNorm + modulate in registers, the 768 x 20 projection against LDS-resident weights (exact fp32)
+        VB_TRY(launch_final_layer_fused(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, v_out, st));
+    } else if (w.final_wp && c.in_channels % 4 == 0 && (int64_t)2 * N * H >= ND) {
         // LN + modulate -> split planes (plane 0 in u, plane 1 in the free expert-hidden buffer), then the projection on the MFMA
         // GEMM in split precision (fp32-class in both modes) with a channel-major epilogue: 62 us -> ~35 us per evaluation
         Planes ln{s.u, (int64_t)(s.Hs - s.u), 2};

@@ -38,7 +38,7 @@ struct GemmDev {
     const float* gate; int gate_ld; int T;
     const int* rows_out; const float* row_scale; const float* y32_in; int n_tiles;
     const float* row_scale2; int scale_split;
-    int grp_rows, grp_tiles;        // uniform groups (per-clip operands): rows per group, row tiles per group; 0 = off
+    int grp_rows, grp_tiles, grp_xcd;   // uniform groups (per-clip operands): rows per group, row tiles per group (0 = off); XCD-affine tile order
     const float* add32; int dup_rows;   // EPI_F32: + add32[m][n]; second copy of the row at m + dup_rows
     int conv_ci, conv_ktap, conv_dil, conv_agrp, conv_arow0; int64_t conv_btap; const float* res32;   // conv-as-GEMM mode (EPI_F32_CT), see GemmArgs
     int ncc, rpx;                   // 128x128 kernel, wide N: column tiles are visited in chunks of ncc (0 = off) over the rpx row tiles of an XCD
@@ -165,6 +165,7 @@ __device__ __forceinline__ void epi_store(const GemmDev& p, int g, int m, int to
         *reinterpret_cast<float4*>(p.out32 + (int64_t)m * p.ldc32 + col) = h;
     } else if constexpr (EPI == EPI_SWIGLU) {
         float o0 = silu_f(v[0]) * v[1], o1 = silu_f(v[2]) * v[3];
+        if (p.row_scale2) { o0 *= scale; o1 *= scale; }      // routed gate weight folded into the hidden row (same two roundings as the P16 path)
         int64_t idx = (int64_t)m * p.ldc + g * p.c_noff_group + (n >> 1);
         bf16_t h0 = f2bf(o0), h1 = f2bf(o1);
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -239,6 +240,9 @@ __device__ __forceinline__ void wave_epilogue(const GemmDev& p, int g, f32x16 (&
         if constexpr (EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES) {
             tok = p.rows_out[slot];
             scale = p.row_scale[tok];
+        }
+        if constexpr (EPI == EPI_SWIGLU) {
+            if (p.row_scale2) scale = (slot < p.scale_split ? p.row_scale : p.row_scale2)[p.a_rows[slot]];
         }
         EpiPre pre[TN][4];
 #pragma unroll
@@ -433,6 +437,9 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
                 if constexpr (EPI == EPI_SCATTER_F32 || EPI == EPI_SCATTER_ADD_PLANES) {
                     tok_[k] = p.rows_out[slot];
                     scale_[k] = p.row_scale[tok_[k]];
+                }
+                if constexpr (EPI == EPI_SWIGLU) {
+                    if (p.row_scale2) scale_[k] = (slot < p.scale_split ? p.row_scale : p.row_scale2)[p.a_rows[slot]];
                 }
                 epi_load<EPI>(p, g, slot, tok_[k], n, pre[k]);
             }
@@ -629,11 +636,19 @@ gemm_bf16_glds_kernel(const GemmDev p) {
         }
         int tmg = rt * 8 + (L & 7);
         if (p.grp_rows > 0) {
-            // uniform groups with per-group B operands (caption-gate scores: one folded key matrix per clip): XCD x = L & 7 serves the
-            // groups x, x + 8, ... - all row tiles of a group on one XCD, its B operand in one L2 (it was fetched by all eight)
-            g = (L & 7) + 8 * (rt / p.grp_tiles);
+            int lt;       // row tile inside the group
+            if (p.grp_xcd) {
+                // per-group B operands (caption-gate scores: one folded key matrix per clip) and a multiple of 8 groups: XCD x = L & 7 serves
+                // the groups x, x + 8, ... - all row tiles of a group on one XCD, its B operand in one L2 (it was fetched by all eight)
+                g = (L & 7) + 8 * (rt / p.grp_tiles);
+                lt = rt % p.grp_tiles;
+            } else {
+                // shared B operand (conv-as-GEMM) or a group count the XCDs do not divide: plain enumeration of (group, row tile)
+                g = tmg / p.grp_tiles;
+                lt = tmg - g * p.grp_tiles;
+            }
             if (g >= p.ngroups) return;
-            row0 = g * p.grp_rows + (rt % p.grp_tiles) * BM; rows_end = (g + 1) * p.grp_rows;
+            row0 = g * p.grp_rows + lt * BM; rows_end = (g + 1) * p.grp_rows;
             if (row0 >= rows_end) return;
         } else if (p.group_off) {
             bool found = false;
@@ -1620,7 +1635,7 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     if constexpr (EPI == EPI_SWIGLU) {
         // SwiGLU (routed w1/w3, gathered rows, grouped): P16 layout, 16-byte hidden stores straight from the accumulators instead of
         // the LDS-staged slab (no epilogue barriers); ldc and the group's column offset must keep the stores 16-byte aligned
-        if (d.K % 64 == 0 && d.N % 16 == 0 && d.ldc % 8 == 0 && d.c_noff_group % 8 == 0 && (!vb_tune().qkv_p16_off || d.row_scale2)) {
+        if (d.K % 64 == 0 && d.N % 16 == 0 && d.ldc % 8 == 0 && d.c_noff_group % 8 == 0 && !vb_tune().qkv_p16_off) {
             hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 2, 0, true>), grid, dim3(NTHREADS), 0, st, d);
             return;
         }
@@ -2095,7 +2110,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             // (threshold 200 tiles since round 3: at 4 clips x 2 branches - one sub-batch of the two-stream configuration, 282 tiles - the
             //  128 x 128 kernel is ahead when another stream shares the GPU: 1287 vs 1280 mel-s/s over three interleaved runs; per-clip
             //  grouped launches with >= 8 clips keep the 128 x 128 kernel for its XCD-affine tile order)
-            else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles && !(a.group_rows > 0 && a.ngroups >= 8 && !vb_tune().no_xcd_groups))
+            else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles && !(a.group_rows > 0 && a.ngroups >= 8 && a.ngroups % 8 == 0 && !vb_tune().no_xcd_groups))
                 cfg = vb_tune().gemm_small;
         }
     }
@@ -2132,11 +2147,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
-    d.grp_rows = 0; d.grp_tiles = 0;
+    d.grp_rows = 0; d.grp_tiles = 0; d.grp_xcd = 0;
     if (a.conv_ci > 0 && (cfg || a.K % 64)) VB_FAIL(VB_E_INVALID, "gemm: conv mode runs on the 128 x 128 DMA kernel (K %% 64 == 0)");
-    if (!cfg && a.group_off && a.group_rows > 0 && a.K % 32 == 0 && (!vb_tune().no_xcd_groups || a.conv_ci > 0)) {      // 128 x 128 DMA kernels only
+    if (!cfg && a.group_off && a.group_rows > 0 && a.K % 32 == 0) {      // 128 x 128 DMA kernels only
         d.grp_rows = a.group_rows; d.grp_tiles = cdiv(a.group_rows, BM);
-        mt = cdiv(a.ngroups, 8) * 8 * d.grp_tiles;
+        d.grp_xcd = (a.conv_ci == 0 && a.ngroups % 8 == 0 && !vb_tune().no_xcd_groups) ? 1 : 0;
+        mt = d.grp_xcd ? a.ngroups * d.grp_tiles : (a.ngroups * d.grp_tiles + 7) / 8 * 8;
     }
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
     d.ncc = 0; d.rpx = (mt + 7) / 8;

@@ -175,6 +175,9 @@ int launch_pool_add(const float* a, const float* b, int B, int C, int T_in, floa
 int launch_transpose_bct_btc(const float* in, int B, int C, int T_in, int T_out, float* out, hipStream_t st);
 int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
                        int rows, int D, int T, int C, float eps, float* out, hipStream_t st);
+bool final_layer_fused_ok(int D, int C);
+int launch_final_layer_fused(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                             int rows, int D, int T, int C, float eps, float* out, hipStream_t st);
 int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_scale, const float* dt_table, const int* step,
                      float dt_val, int has_uncond, hipStream_t st);
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,

@@ -6,6 +6,8 @@
 // each lane runs a private K-long dot product for ONE (row, output) pair - the 16 lanes of an output share the
 // weight address (one broadcast 16-B fetch), the 16 rows sit in distinct LDS banks (row pitch K+4 floats) - so
 // there is no cross-lane reduction at all (the v1 kernel spent its time in 96 shuffles per output).
+#include <type_traits>
+
 #include "kernels.h"
 
 #define RL_R 16
@@ -118,6 +120,74 @@ int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const flo
 int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x2_mod, const float* W, const float* bias, int R,
                      int N, int K, int act_in, float* out, int out_ld, hipStream_t st) {
     return launch_rowlin<0>(x, x_ld, nullptr, x2, x2_ld, x2_mod, nullptr, nullptr, 0, 1, 0.f, W, bias, R, N, K, act_in, out, out_ld, st);
+}
+// FinalLayer, dedicated kernel (round 3): LN(no affine) -> modulate -> Linear(D -> C <= 64) -> out[b][c][t], one WAVE per token row.
+// The projection is 768 x 20: as an MFMA GEMM it fills 16 % of a 128-wide tile and needed its input as split planes first (LN + modulate
+// kernel 16 us + GEMM 19 us per evaluation); here a row's 12 values per lane stay in registers from the LayerNorm on, the weight matrix
+// sits in LDS (61 KB, read as conflict-free float4), and every output is one wave reduction - exact fp32 arithmetic, memory-bound on
+// reading h once.
+template <int NQ>      // D = 256 * NQ
+__global__ void __launch_bounds__(256) final_layer_kernel(const float* __restrict__ h, const float* __restrict__ shift,
+                                                         const float* __restrict__ scale, int mod_ld, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, int rows, int T, int C, float eps, float* out) {
+    constexpr int D = 256 * NQ;
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [C][D]
+    for (int id = threadIdx.x * 4; id < C * D; id += 1024) *reinterpret_cast<float4*>(wl + id) = *reinterpret_cast<const float4*>(W + id);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xr = h + (int64_t)row * D;
+        float4 x[NQ];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { x[i] = *reinterpret_cast<const float4*>(xr + lane * 4 + 256 * i); s += (x[i].x + x[i].y) + (x[i].z + x[i].w); }
+        const float mean = wave_sum(s) / (float)D;
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
+            vs += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+        }
+        const float rs = rsqrtf(wave_sum(vs) / (float)D + eps);
+        const int b = row / T, t = row - b * T;
+        const float* sc = scale + (int64_t)b * mod_ld; const float* sh = shift + (int64_t)b * mod_ld;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const float4 a = *reinterpret_cast<const float4*>(sc + lane * 4 + 256 * i), c = *reinterpret_cast<const float4*>(sh + lane * 4 + 256 * i);
+            x[i].x = x[i].x * rs * (1.f + a.x) + c.x; x[i].y = x[i].y * rs * (1.f + a.y) + c.y;
+            x[i].z = x[i].z * rs * (1.f + a.z) + c.z; x[i].w = x[i].w * rs * (1.f + a.w) + c.w;
+        }
+        float res = 0.f;
+        for (int n = 0; n < C; ++n) {
+            const float* wr = wl + n * D + lane * 4;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(wr + 256 * i);
+                acc += (x[i].x * w.x + x[i].y * w.y) + (x[i].z * w.z + x[i].w * w.w);
+            }
+            acc = wave_sum(acc);
+            if (lane == n) res = acc;
+        }
+        if (lane < C) out[((int64_t)b * C + lane) * T + t] = res + (bias ? bias[lane] : 0.f);
+    }
+}
+bool final_layer_fused_ok(int D, int C) { return (D == 256 || D == 512 || D == 768 || D == 1024) && C <= 64 && (size_t)C * D * 4 <= 96 * 1024; }
+int launch_final_layer_fused(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                             int rows, int D, int T, int C, float eps, float* out, hipStream_t st) {
+    if (!final_layer_fused_ok(D, C)) VB_FAIL(VB_E_INVALID, "final_layer_fused: D=%d C=%d unsupported", D, C);
+    const size_t sh = (size_t)C * D * sizeof(float);
+    const int grid = min(cdiv(rows, 4), 512);
+    static OnceFlags attr[4];
+    auto go = [&](auto nq) {
+        constexpr int NQ = decltype(nq)::value;
+        vb_set_max_lds_once(attr[NQ - 1], reinterpret_cast<const void*>(final_layer_kernel<NQ>), 96 * 1024);
+        hipLaunchKernelGGL(final_layer_kernel<NQ>, dim3(grid), dim3(256), sh, st, h, shift, scale, mod_ld, W, bias, rows, T > 0 ? T : 1, C, eps, out);
+    };
+    if (D == 256) go(std::integral_constant<int, 1>()); else if (D == 512) go(std::integral_constant<int, 2>());
+    else if (D == 768) go(std::integral_constant<int, 3>()); else go(std::integral_constant<int, 4>());
+    VB_CHECK_LAUNCH();
+    return VB_OK;
 }
 // FinalLayer (vocal2music_moe.py:287-291): LN(no affine, eps) -> modulate -> Linear(D->C) -> out[b][c][t]
 int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
