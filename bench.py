@@ -229,6 +229,7 @@ def parse():
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
     ap.add_argument("--scale", type=float, default=3.0)
     ap.add_argument("--streams", type=int, default=None, help="independent sub-batches per GPU, one HIP stream + host thread each")
+    ap.add_argument("--split", default=None, help="explicit clips per sub-batch, e.g. 5,3 (default: --batch spread evenly over --streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated", action="store_true", help="skip the untimed one-stream pass that measures every kernel class alone")
     ap.add_argument("--no-parity-check", action="store_true")
@@ -501,7 +502,11 @@ def main():
     B = args.batch
     assert S <= B, "--streams must not exceed --batch"
     sizes = [B // S + (1 if i < B % S else 0) for i in range(S)]        # uneven splits allowed (8 clips on 3 streams: 3 + 3 + 2)
-    Bs = "+".join(str(n) for n in sizes) if B % S else str(B // S)
+    if args.split:
+        sizes = [int(v) for v in args.split.split(",")]
+        assert sum(sizes) == B and all(v > 0 for v in sizes), "--split must list positive sub-batch sizes that add up to --batch"
+        S = len(sizes)
+    Bs = "+".join(str(n) for n in sizes) if (B % S or args.split) else str(B // S)
     idx, dts = vm.euler_tables(args.flow_steps + 1)
 
     def make_worker(nclips, clip_base, share=None):

@@ -1133,7 +1133,13 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
         const int jx = L >> 3;
         tile_n = jx % nN;
         int tmg = (jx / nN) * 8 + (L & 7);
-        if (p.group_off) {
+        if (p.grp_rows > 0) {
+            // uniform groups (conv-as-GEMM: one clip per group, shared weights): plain enumeration of (group, row tile)
+            g = tmg / p.grp_tiles;
+            if (g >= p.ngroups) return;
+            row0 = g * p.grp_rows + (tmg - g * p.grp_tiles) * BMB; rows_end = (g + 1) * p.grp_rows;
+            if (row0 >= rows_end) return;
+        } else if (p.group_off) {
             bool found = false;
             for (int gi = 0; gi < p.ngroups; ++gi) {
                 int lo = p.group_off[gi], hi = p.group_off[gi + 1];
@@ -1161,7 +1167,10 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
             const int c = cs ^ ((r >> 1) & 7);
             int slot = row0 + r;
             if (slot >= rows_end) slot = row0;
-            const int arow = p.a_rows ? p.a_rows[slot] : slot;
+            int arow = p.a_rows ? p.a_rows[slot] : slot;
+            if constexpr (EPI == EPI_F32_CT) {
+                if (p.conv_ktap > 0) arow = g * p.conv_agrp + p.conv_arow0 + (slot - g * p.grp_rows);
+            }
             asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
         }
 #pragma unroll
@@ -1177,8 +1186,15 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
         const int st = t % NSTB;
         const int seg = t / KT;
         const int k0 = (t - seg * KT) * 64;
-        const int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
-        const int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+        int64_t ao = (seg == 1 ? p.a_plane : 0) + k0;
+        int64_t bo = (seg == 2 ? p.b_plane : 0) + k0;
+        if constexpr (EPI == EPI_F32_CT) {
+            if (p.conv_ktap > 0) {       // conv mode: k-tile -> (tap, channel chunk), see gemm_bf16_glds_kernel
+                const int kt = t - seg * KT, tap = kt / p.conv_ktap, c0 = (kt - tap * p.conv_ktap) * 64;
+                ao = (seg == 1 ? p.a_plane : 0) + (int64_t)tap * p.conv_dil * p.lda + c0;
+                bo = (seg == 2 ? p.b_plane : 0) + (int64_t)tap * p.conv_btap + c0;
+            }
+        }
         unsigned char* sa = ldsb + st * STAGE;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
@@ -2136,7 +2152,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
     }
 #endif
-    if (a.conv_ci > 0) cfg = 0;
+    if (a.conv_ci > 0) {
+        // conv-as-GEMM: 128 x 128 tiles, or 64 x 64 (three workgroups per CU) when 128 x 128 would make fewer than 200 workgroups - one or two
+        // clips; same k order in both, so a clip's bits do not depend on the batch
+        const int64_t t22c = (int64_t)a.ngroups * cdiv(a.group_rows, BM) * cdiv(a.N, BN);
+        cfg = (vb_tune().gemm_small == 11 && t22c < vb_tune().gemm_small_tiles) ? 11 : 0;
+    }
     if (cfg == 23) {     // 128 x 192, two per CU, gated-residual epilogue (gemm_bf16_wide_resid_kernel)
         if (a.epi != EPI_RESID_GATE || a.group_off || a.N % 192 || a.K % 64) VB_FAIL(VB_E_INVALID, "gemm: tile 23 serves the plain gated-residual GEMM only");
         d.n_tiles = a.N / 192;
@@ -2148,9 +2169,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
     d.grp_rows = 0; d.grp_tiles = 0; d.grp_xcd = 0;
-    if (a.conv_ci > 0 && (cfg || a.K % 64)) VB_FAIL(VB_E_INVALID, "gemm: conv mode runs on the 128 x 128 DMA kernel (K %% 64 == 0)");
-    if (!cfg && a.group_off && a.group_rows > 0 && a.K % 32 == 0) {      // 128 x 128 DMA kernels only
-        d.grp_rows = a.group_rows; d.grp_tiles = cdiv(a.group_rows, BM);
+    if (a.conv_ci > 0 && ((cfg != 0 && cfg != 11) || a.K % 64)) VB_FAIL(VB_E_INVALID, "gemm: conv mode runs on the 128 x 128 / 64 x 64 DMA kernels (K %% 64 == 0)");
+    if ((!cfg || (cfg == 11 && a.conv_ci > 0)) && a.group_off && a.group_rows > 0 && a.K % 32 == 0) {      // uniform groups: 128 x 128 kernel; 64 x 64 in conv mode
+        d.grp_rows = a.group_rows; d.grp_tiles = cdiv(a.group_rows, bm);
         d.grp_xcd = (a.conv_ci == 0 && a.ngroups % 8 == 0 && !vb_tune().no_xcd_groups) ? 1 : 0;
         mt = d.grp_xcd ? a.ngroups * d.grp_tiles : (a.ngroups * d.grp_tiles + 7) / 8 * 8;
     }
