@@ -247,7 +247,7 @@ def test_route_bucket(lib, N, E):
         assert torch.equal(sel, want), f"group {g}: stable order violated"      # stable: tokens in ascending order
 
 
-@pytest.mark.parametrize("N,E", [(5000, 4), (12032, 4), (6016, 2), (777, 3)])
+@pytest.mark.parametrize("N,E", [(5000, 4), (12032, 4), (6016, 2), (777, 3), (1504, 4), (4096, 4), (1, 2)])
 def test_route_bucket_pairs(lib, N, E):
     """pair mode: one rank per token by (caption, acoustic) expert pair; caption slots = pair slots (caption-major), acoustic slots =
     the same buckets acoustic-major; group_off / perm stay a valid bucketing by expert, tokens ascending inside a PAIR bucket"""

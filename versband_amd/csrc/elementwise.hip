@@ -539,12 +539,14 @@ __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restric
 // Same result, bit for bit (stable: ascending token order inside a group).
 #define BKS_T 1024
 #define BKS_CH 4            // chunks of 1024 tokens: N <= 4096
+template <bool PAIRS>
 __global__ void __launch_bounds__(BKS_T) bucket_small_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E,
-                                                            int* group_off, int* perm) {
+                                                            int* group_off, int* perm, int* pair_off, int* pair_pa) {
     __shared__ int cnt[BKS_CH * 16][BK_G];      // [chunk * 16 + wave][group]: count, then exclusive prefix inside the group
-    __shared__ int gbase[BK_G + 1];
+    __shared__ int gbase[BK_G + 1];             // group start (pair mode: caption-major start of the pair bucket)
+    __shared__ int gbase2[BK_G];                // pair mode: acoustic-major start of the pair bucket (slots [N, 2N))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = 2 * E;
+    const int G = PAIRS ? E * E : 2 * E;
     const int nch = (N + BKS_T - 1) / BKS_T;
     int gc[BKS_CH], ga[BKS_CH], rc[BKS_CH], ra[BKS_CH];
     const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -553,43 +555,74 @@ __global__ void __launch_bounds__(BKS_T) bucket_small_kernel(const int* __restri
         gc[ch] = -1; ga[ch] = -1; rc[ch] = 0; ra[ch] = 0;
         if (ch < nch) {
             const int n = ch * BKS_T + tid;
-            if (n < N) { gc[ch] = ic[n]; ga[ch] = E + ia[n]; }
+            if (n < N) {
+                if (PAIRS) { gc[ch] = ic[n] * E + ia[n]; } else { gc[ch] = ic[n]; ga[ch] = E + ia[n]; }
+            }
             for (int g = 0; g < G; ++g) {
-                const unsigned long long m = __ballot(g < E ? (gc[ch] == g) : (ga[ch] == g));
+                const unsigned long long m = __ballot(PAIRS ? (gc[ch] == g) : (g < E ? (gc[ch] == g) : (ga[ch] == g)));
                 if (lane == 0) cnt[ch * 16 + wave][g] = __popcll(m);
                 if (g == gc[ch]) rc[ch] = __popcll(m & lower);
-                if (g == ga[ch]) ra[ch] = __popcll(m & lower);
+                if (!PAIRS && g == ga[ch]) ra[ch] = __popcll(m & lower);
             }
         }
     }
     __syncthreads();
+    __shared__ int tot[BK_G];
     if (tid < G) {
         int run = 0;
         for (int i = 0; i < nch * 16; ++i) { const int c = cnt[i][tid]; cnt[i][tid] = run; run += c; }
-        gbase[tid + 1] = run;          // group total for now
+        tot[tid] = run;
     }
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int g = 0; g < G; ++g) { const int t = gbase[g + 1]; gbase[g] = run; run += t; }
-        gbase[G] = run;
+    if (tid < G) {
+        // every group works out its own start from the totals (no serial section): caption-major prefix, and in pair mode the
+        // acoustic-major start of the same bucket (everything with a smaller acoustic expert, then the same a with a smaller c)
+        int before = 0;
+        for (int g = 0; g < tid; ++g) before += tot[g];
+        gbase[tid] = before;
+        if (tid == G - 1) gbase[G] = before + tot[tid];
+        if (PAIRS) {
+            const int c = tid / E, a = tid - c * E;
+            int b2 = 0;
+            for (int g2 = 0; g2 < G; ++g2) {
+                const int c2 = g2 / E, a2 = g2 - c2 * E;
+                if (a2 < a || (a2 == a && c2 < c)) b2 += tot[g2];
+            }
+            gbase2[tid] = N + b2;
+        }
     }
     __syncthreads();
-    if (tid <= G) group_off[tid] = gbase[tid];
+    if (PAIRS) {
+        if (tid <= G) pair_off[tid] = gbase[tid];
+        if (tid < E) { group_off[tid] = gbase[tid * E]; group_off[E + tid] = gbase2[tid]; }      // caption group c = pair (c, 0); acoustic a = pair (0, a)
+        if (tid == 0) { group_off[E] = N; group_off[2 * E] = 2 * N; }
+    } else {
+        if (tid <= G) group_off[tid] = gbase[tid];
+    }
 #pragma unroll
     for (int ch = 0; ch < BKS_CH; ++ch) {
         const int n = ch * BKS_T + tid;
         if (ch < nch && n < N) {
-            perm[gbase[gc[ch]] + cnt[ch * 16 + wave][gc[ch]] + rc[ch]] = n;
-            perm[gbase[ga[ch]] + cnt[ch * 16 + wave][ga[ch]] + ra[ch]] = n;
+            if (PAIRS) {
+                const int r = cnt[ch * 16 + wave][gc[ch]] + rc[ch];
+                const int pc = gbase[gc[ch]] + r, pa = gbase2[gc[ch]] + r;
+                perm[pc] = n;
+                perm[pa] = n;
+                pair_pa[pc] = pa;
+            } else {
+                perm[gbase[gc[ch]] + cnt[ch * 16 + wave][gc[ch]] + rc[ch]] = n;
+                perm[gbase[ga[ch]] + cnt[ch * 16 + wave][ga[ch]] + ra[ch]] = n;
+            }
         }
     }
 }
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off, int* pair_pa) {
     if (E > 16) VB_FAIL(VB_E_INVALID, "bucket: E=%d > 16", E);
     const bool pairs = pair_off != nullptr;
-    if (!pairs && N <= BKS_T * BKS_CH) {
-        hipLaunchKernelGGL(bucket_small_kernel, dim3(1), dim3(BKS_T), 0, st, ic, ia, N, E, group_off, perm);
+    if (pairs && E * E > 16) VB_FAIL(VB_E_INVALID, "bucket: pair mode needs E*E <= 16 (E=%d)", E);
+    if (N <= BKS_T * BKS_CH) {
+        if (pairs) hipLaunchKernelGGL(bucket_small_kernel<true>, dim3(1), dim3(BKS_T), 0, st, ic, ia, N, E, group_off, perm, pair_off, pair_pa);
+        else hipLaunchKernelGGL(bucket_small_kernel<false>, dim3(1), dim3(BKS_T), 0, st, ic, ia, N, E, group_off, perm, nullptr, nullptr);
         VB_CHECK_LAUNCH();
         return VB_OK;
     }
