@@ -81,7 +81,7 @@ struct VbTune {
     bool conv_direct_epi = false, gate_unfolded = false, stem_f32 = false, band_unfused = false, moe_unfused = false, score_fused = false, no_graph = false;
     int w2_pair = 1;
     bool qkv_p16_off = false, no_xcd_groups = false;
-    int wide_resid = 1;
+    int wide_resid = 1, big_tile_min_k = 384;
     bool proj_in_conv = false, conv_gemm_off = false, final_gemm = false;
 };
 const VbTune& vb_tune();

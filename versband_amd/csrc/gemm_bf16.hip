@@ -2122,7 +2122,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             const int64_t t22 = (a.group_off ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
             const int64_t t23 = (int64_t)cdiv(a.M, BM) * (a.N / 192);
             if (a.epi == EPI_RESID_GATE && !a.group_off && gz == 1 && a.N % 192 == 0 && t22 > 512 && t23 <= 512 && vb_tune().wide_resid) cfg = 23;
-            else if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out) cfg = 33;      // (row-scatter epilogues measured slower on it)
+            // (K >= 384 since round 3: at one clip the band experts' K = 192 first product took the 192 x 192 one-per-CU kernel - three
+            //  k-iterations under a 24-KB-per-stage ring, 18 us - where 128 x 128 tiles run ~8: one 20 s clip 40.2 -> 38.2 ms)
+            else if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out && a.K >= vb_tune().big_tile_min_k) cfg = 33;      // (row-scatter epilogues measured slower on it)
             // small problems (one or two clips): 128x128 tiles leave most CUs idle and a tile's 12 k-iterations are pure DMA latency;
             // 64x64 tiles (three workgroups per CU) make 4x the tiles.  VB_GEMM_SMALL=0 keeps the 128x128 kernel, 21 takes 128x64.
             // (threshold 200 tiles since round 3: at 4 clips x 2 branches - one sub-batch of the two-stream configuration, 282 tiles - the

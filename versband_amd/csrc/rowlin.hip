@@ -126,6 +126,21 @@ int launch_gemv_rows(const float* x, int x_ld, const float* x2, int x2_ld, int x
 // kernel 16 us + GEMM 19 us per evaluation); here a row's 12 values per lane stay in registers from the LayerNorm on, the weight matrix
 // sits in LDS (61 KB, read as conflict-free float4), and every output is one wave reduction - exact fp32 arithmetic, memory-bound on
 // reading h once.
+// wave-wide sum WITHOUT the LDS crossbar: row-level butterflies and broadcasts as DPP modifiers of VALU adds (quad_perm, row_ror 4 / 8,
+// row_bcast 15 / 31), total in lane 63, handed to every lane through an SGPR.  (__shfl_xor is ds_bpermute on gfx9: 6 LDS-pipe
+// instructions per sum - 20 sums per token row made the first version of the kernel below LDS-issue-bound, 52 us at 12 032 rows.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto mv = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += mv(v, std::integral_constant<int, 0xb1>());     // quad_perm [1,0,3,2]
+    v += mv(v, std::integral_constant<int, 0x4e>());     // quad_perm [2,3,0,1]
+    v += mv(v, std::integral_constant<int, 0x124>());    // row_ror 4
+    v += mv(v, std::integral_constant<int, 0x128>());    // row_ror 8
+    v += mv(v, std::integral_constant<int, 0x142>());    // row_bcast 15
+    v += mv(v, std::integral_constant<int, 0x143>());    // row_bcast 31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 template <int NQ>      // D = 256 * NQ
 __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restrict__ h, const float* __restrict__ shift,
                                                          const float* __restrict__ scale, int mod_ld, const float* __restrict__ W,
@@ -135,41 +150,52 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
     for (int id = threadIdx.x * 4; id < C * D; id += 1024) *reinterpret_cast<float4*>(wl + id) = *reinterpret_cast<const float4*>(W + id);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float* xr = h + (int64_t)row * D;
-        float4 x[NQ];
-        float s = 0.f;
+    // a wave walks PAIRS of rows: every weight quad read from LDS serves both (the LDS reads, not the 240 FMAs per row, set the pace)
+    for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < rows; row0 += gridDim.x * 8) {
+        float4 x[2][NQ];
+        int bb[2], tt[2];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) { x[i] = *reinterpret_cast<const float4*>(xr + lane * 4 + 256 * i); s += (x[i].x + x[i].y) + (x[i].z + x[i].w); }
-        const float mean = wave_sum(s) / (float)D;
-        float vs = 0.f;
+        for (int r = 0; r < 2; ++r) {
+            const int row = min(row0 + r, rows - 1);
+            const float* xr = h + (int64_t)row * D;
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
-            vs += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+            for (int i = 0; i < NQ; ++i) { x[r][i] = *reinterpret_cast<const float4*>(xr + lane * 4 + 256 * i); s += (x[r][i].x + x[r][i].y) + (x[r][i].z + x[r][i].w); }
+            const float mean = wave_sum_dpp(s) / (float)D;
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                x[r][i].x -= mean; x[r][i].y -= mean; x[r][i].z -= mean; x[r][i].w -= mean;
+                vs += (x[r][i].x * x[r][i].x + x[r][i].y * x[r][i].y) + (x[r][i].z * x[r][i].z + x[r][i].w * x[r][i].w);
+            }
+            const float rs = rsqrtf(wave_sum_dpp(vs) / (float)D + eps);
+            bb[r] = row / T; tt[r] = row - bb[r] * T;
+            const float* sc = scale + (int64_t)bb[r] * mod_ld; const float* sh = shift + (int64_t)bb[r] * mod_ld;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const float4 a = *reinterpret_cast<const float4*>(sc + lane * 4 + 256 * i), c = *reinterpret_cast<const float4*>(sh + lane * 4 + 256 * i);
+                x[r][i].x = x[r][i].x * rs * (1.f + a.x) + c.x; x[r][i].y = x[r][i].y * rs * (1.f + a.y) + c.y;
+                x[r][i].z = x[r][i].z * rs * (1.f + a.z) + c.z; x[r][i].w = x[r][i].w * rs * (1.f + a.w) + c.w;
+            }
         }
-        const float rs = rsqrtf(wave_sum(vs) / (float)D + eps);
-        const int b = row / T, t = row - b * T;
-        const float* sc = scale + (int64_t)b * mod_ld; const float* sh = shift + (int64_t)b * mod_ld;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const float4 a = *reinterpret_cast<const float4*>(sc + lane * 4 + 256 * i), c = *reinterpret_cast<const float4*>(sh + lane * 4 + 256 * i);
-            x[i].x = x[i].x * rs * (1.f + a.x) + c.x; x[i].y = x[i].y * rs * (1.f + a.y) + c.y;
-            x[i].z = x[i].z * rs * (1.f + a.z) + c.z; x[i].w = x[i].w * rs * (1.f + a.w) + c.w;
-        }
-        float res = 0.f;
+        float res0 = 0.f, res1 = 0.f;
         for (int n = 0; n < C; ++n) {
             const float* wr = wl + n * D + lane * 4;
-            float acc = 0.f;
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const float4 w = *reinterpret_cast<const float4*>(wr + 256 * i);
-                acc += (x[i].x * w.x + x[i].y * w.y) + (x[i].z * w.z + x[i].w * w.w);
+                a0 += (x[0][i].x * w.x + x[0][i].y * w.y) + (x[0][i].z * w.z + x[0][i].w * w.w);
+                a1 += (x[1][i].x * w.x + x[1][i].y * w.y) + (x[1][i].z * w.z + x[1][i].w * w.w);
             }
-            acc = wave_sum(acc);
-            if (lane == n) res = acc;
+            a0 = wave_sum_dpp(a0); a1 = wave_sum_dpp(a1);
+            if (lane == n) { res0 = a0; res1 = a1; }
         }
-        if (lane < C) out[((int64_t)b * C + lane) * T + t] = res + (bias ? bias[lane] : 0.f);
+        if (lane < C) {
+            const float bv = bias ? bias[lane] : 0.f;
+            out[((int64_t)bb[0] * C + lane) * T + tt[0]] = res0 + bv;
+            if (row0 + 1 < rows) out[((int64_t)bb[1] * C + lane) * T + tt[1]] = res1 + bv;
+        }
     }
 }
 bool final_layer_fused_ok(int D, int C) { return (D == 256 || D == 512 || D == 768 || D == 1024) && C <= 64 && (size_t)C * D * 4 <= 96 * 1024; }
@@ -177,7 +203,7 @@ int launch_final_layer_fused(const float* h, const float* shift, const float* sc
                              int rows, int D, int T, int C, float eps, float* out, hipStream_t st) {
     if (!final_layer_fused_ok(D, C)) VB_FAIL(VB_E_INVALID, "final_layer_fused: D=%d C=%d unsupported", D, C);
     const size_t sh = (size_t)C * D * sizeof(float);
-    const int grid = min(cdiv(rows, 4), 512);
+    const int grid = min(cdiv(rows, 8), 512);
     static OnceFlags attr[4];
     auto go = [&](auto nq) {
         constexpr int NQ = decltype(nq)::value;
