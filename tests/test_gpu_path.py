@@ -464,13 +464,14 @@ def test_vae_wide_convs_as_gemm_match_the_conv_kernel(ctx, monkeypatch, B, T):
     assert rel_l2(m1, ref) < 2e-4, describe("VAE decode vs oracle", m1, ref)
 
 
-@pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_NO_XCD_GROUPS"])
-@pytest.mark.parametrize("prec,B,T", [("bf16", 4, 752), ("split", 3, 700)])
+@pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_NO_XCD_GROUPS", "VB_BIG_TILE_MIN_K=0", "VB_WIDE_RESID=0"])
+@pytest.mark.parametrize("prec,B,T", [("bf16", 4, 752), ("split", 3, 700), ("bf16", 1, 752), ("bf16", 8, 752)])
 def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T, knob):
     """The QKV + RoPE GEMM fills its weight tile with permuted source rows so a lane's accumulator holds 16 CONSECUTIVE output columns
     (16-byte q / k stores and RoPE-table loads instead of 8-byte ones): the same values in other lanes - the DiT output must not change
     by a bit against the quad layout (VB_QKV_P16_OFF=1), in both precisions, full and ragged row tiles.  Same for the XCD-affine
-    tile order of the per-clip grouped caption-gate GEMM (VB_NO_XCD_GROUPS=1 restores the interleaved order): same tiles, other CUs."""
+    tile order of the per-clip grouped caption-gate GEMM (VB_NO_XCD_GROUPS=1 restores the interleaved order): same tiles, other CUs;
+    the K >= 384 rule of the 192 x 192 kernel (VB_BIG_TILE_MIN_K=0) and the 128 x 192 gated-residual kernel at 8 clips (VB_WIDE_RESID=0): same k order, other tiles."""
     eng = engines[(4, prec)]
     Lc = 80
     inp = clip_batch(B, T, Lc)
@@ -479,11 +480,12 @@ def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T
     v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
     torch.cuda.synchronize()
     v1, r1 = v1.clone(), r1.clone()
-    monkeypatch.setenv(knob, "1")
+    kname, _, kval = knob.partition("=")
+    monkeypatch.setenv(kname, kval or "1")
     L.load().vb_tune_reload()
     v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
     torch.cuda.synchronize()
-    monkeypatch.delenv(knob)
+    monkeypatch.delenv(kname)
     L.load().vb_tune_reload()
     assert torch.isfinite(v1).all() and torch.equal(r1, r2)
     assert torch.equal(v1, v2), describe("P16 vs quad column layout of the QKV epilogue", v1, v2)
