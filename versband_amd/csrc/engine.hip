@@ -37,6 +37,7 @@ static void tune_load() {
     t.w2_pair = env_int("VB_W2_PAIR", 1);
     t.qkv_p16_off = getenv("VB_QKV_P16_OFF") != nullptr;
     t.no_xcd_groups = getenv("VB_NO_XCD_GROUPS") != nullptr;
+    t.qkv_vt16_off = getenv("VB_QKV_VT16_OFF") != nullptr;
     t.wide_resid = env_int("VB_WIDE_RESID", 1);
     t.big_tile_min_k = env_int("VB_BIG_TILE_MIN_K", 384);
     t.proj_in_conv = getenv("VB_PROJ_IN_CONV") != nullptr;

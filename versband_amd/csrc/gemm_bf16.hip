@@ -45,6 +45,7 @@ struct GemmDev {
     bf16_t* q; int64_t q_plane; bf16_t* k; int64_t k_plane; bf16_t* vt; int64_t vt_plane; int qkv_np;
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
     float rT, rhd, rD;              // reciprocals for fdiv(): the epilogues decompose row -> (clip, t) and column -> (head, d)
+    int no_vt16;                    // QKV P16: keep the V third on the row-per-lane layout (VB_QKV_VT16_OFF: bit-identity switch)
     unsigned long long* trace;      // tuning only (vbdbg_gemm_trace): per block {t_start, t_loop_end, t_end, hw ids}
     int abl;                        // tuning only (VB_GEMM_ABLATE): 6 = QKV without the V^T stores, 7 = without the q/k stores, 8 = without the RoPE table loads
 };
@@ -313,6 +314,39 @@ __device__ __forceinline__ void wave_epilogue_qkv_p16(const GemmDev& p, f32x16 (
                 const int64_t base = ((int64_t)(b * p.H + h) * p.hd + d0) * p.Tpad + t;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) store1p(p.vt, p.vt_plane, p.qkv_np, base + (int64_t)e * p.Tpad, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+// V third of the QKV projection with the MFMA operands' roles exchanged (the workgroup reads the weight tile as its "row" operand and the
+// token tile - source rows permuted - as its "column" operand): a lane then owns ONE head-dim column d and 16 CONSECUTIVE tokens per
+// 32 x 32 tile, i.e. 32 contiguous bytes of the per-head V^T image [d][t] the attention kernel reads - two 16-byte stores where the
+// row-per-lane layout needed sixteen 2-byte ones.  Same products, same k order: bit-identical.  Needs T % 16 == 0.
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_vt_p16(const GemmDev& p, f32x16 (&acc)[TM][TN], int d_base, int tok_base, int rows_end, int frow, int fk) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int n = d_base + i * 32 + frow;             // output column of the projection (this lane's weight row)
+        if (n >= p.N) continue;
+        const int nn = n - 2 * p.D;
+        const int h = fdiv(nn, p.rhd), d = nn - h * p.hd;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int m0 = tok_base + j * 32 + 16 * fk;
+            if (m0 >= rows_end) continue;
+            const int b = fdiv(m0, p.rT), t = m0 - b * p.T;
+            const int64_t base = ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t;
+            float o[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = acc[i][j][e];
+            if (m0 + 15 < rows_end) {
+                store8p(p.vt, p.vt_plane, p.qkv_np, base, o);
+                store8p(p.vt, p.vt_plane, p.qkv_np, base + 8, o + 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (m0 + e < rows_end) store1p(p.vt, p.vt_plane, p.qkv_np, base + e, o[e]);
             }
         }
     }
@@ -668,6 +702,9 @@ gemm_bf16_glds_kernel(const GemmDev p) {
     const int n0 = tile_n * BN;
     const int KT = (ABL == 5) ? 0 : p.K / BKT;
     const int total = KT * p.nseg;
+    // QKV, P16: a tile of the V third exchanges the operands' roles (see wave_epilogue_vt_p16) - the permutation then belongs to the TOKEN rows
+    bool vsec = false;
+    if constexpr (P16 && EPI == EPI_QKV_ROPE) vsec = n0 >= 2 * p.D && (p.T & 15) == 0 && !p.no_vt16;
 
     const bf16_t* asrc[SPW]; const bf16_t* bsrc[SPW];
 #pragma unroll
@@ -676,14 +713,14 @@ gemm_bf16_glds_kernel(const GemmDev p) {
         const int r = RS * s + lane / CH;
         const int cs = lane % CH;
         const int c = (BKT == 64) ? (cs ^ ((r >> 1) & 7)) : (cs ^ ((r >> 2) & 3));
-        int slot = row0 + r;
+        int slot = row0 + (vsec ? p16_src_row(r) : r);
         if (slot >= rows_end) slot = row0;
         int arow = p.a_rows ? p.a_rows[slot] : slot;
         if constexpr (EPI == EPI_F32_CT) {
             if (p.conv_ktap > 0) arow = g * p.conv_agrp + p.conv_arow0 + (slot - g * p.grp_rows);      // clip g's padded plane image, row of tap 0
         }
         asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
-        int nrow = n0 + (P16 ? p16_src_row(r) : r);
+        int nrow = n0 + ((P16 && !vsec) ? p16_src_row(r) : r);
         if (nrow >= p.N) nrow = 0;
         bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
     }
@@ -729,8 +766,9 @@ gemm_bf16_glds_kernel(const GemmDev p) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();           // tile t landed everywhere; everyone finished reading stage (t-1)%NST
         if (ABL != 1 && t + NST - 1 < total) issue(t + NST - 1);
-        const unsigned char* As = &lds[(st * 2 + 0) * OPB];
-        const unsigned char* Bs = &lds[(st * 2 + 1) * OPB];
+        // (V third of QKV: the weight tile plays the token tile's part and vice versa - a uniform pointer exchange, same code)
+        const unsigned char* As = &lds[(st * 2 + (vsec ? 1 : 0)) * OPB];
+        const unsigned char* Bs = &lds[(st * 2 + (vsec ? 0 : 1)) * OPB];
         // fragment reads are software-pipelined in registers: the ds_reads of k-step ks+1 are issued before the MFMAs of
         // k-step ks (the compiler otherwise reuses one register set and serialises read -> wait -> 4 MFMA per k-step)
         bf16x8 af[2][2], bf[2][2];
@@ -780,7 +818,10 @@ gemm_bf16_glds_kernel(const GemmDev p) {
     } else {
         // (conv-as-GEMM, EPI_F32_CT: a channel-major epilogue staged through LDS - 16-byte residual loads and stores - measured the same
         //  as the direct 4-byte one, 234 vs 230 us per VAE layer: these launches are mainloop-bound at K = 1920 .. 7680; not kept)
-        if constexpr (P16 && EPI == EPI_QKV_ROPE) wave_epilogue_qkv_p16<2, 2>(p, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
+        if constexpr (P16 && EPI == EPI_QKV_ROPE) {
+            if (vsec) wave_epilogue_vt_p16<2, 2>(p, acc, n0 + wr * 64, row0 + wc * 64, rows_end, frow, fk);
+            else wave_epilogue_qkv_p16<2, 2>(p, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
+        }
         else if constexpr (P16 && EPI == EPI_SWIGLU) wave_epilogue_swiglu_p16<2, 2>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
         else if constexpr (STAGED_EPI(EPI)) staged_epilogue<EPI, 2, 2>(p, g, acc, reinterpret_cast<float*>(lds), row0, rows_end, n0, tid, wr, wc, frow, fk);
         else wave_epilogue<EPI>(p, g, acc, row0 + wr * 64, rows_end, n0 + wc * 64, frow, fk);
@@ -2089,7 +2130,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
     d.rT = 1.0f / (float)d.T; d.rhd = 1.0f / (float)d.hd; d.rD = 1.0f / (float)d.D;
     if (a.M >= (1 << 21) || (int64_t)a.N * (a.ngroups > 0 ? a.ngroups : 1) >= (1 << 21)) VB_FAIL(VB_E_INVALID, "gemm: index ranges exceed fdiv()");
-    d.trace = g_gemm_trace; d.abl = vb_tune().gemm_ablate;
+    d.trace = g_gemm_trace; d.abl = vb_tune().gemm_ablate; d.no_vt16 = vb_tune().qkv_vt16_off ? 1 : 0;
     const double gz_ = (a.group_off || a.ngroups <= 1) ? 1.0 : (double)a.ngroups;        // groups that share the row range multiply the work
     const double npl_ = a.nseg == 3 ? 2.0 : 1.0, MN_ = (double)a.M * a.N * gz_;
     double ob_;                                                                         // result (+ read-modify) bytes of the epilogue
