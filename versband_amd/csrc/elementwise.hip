@@ -534,6 +534,9 @@ __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restric
         }
     }
 }
+// (Round 3, measured and removed: count + place as ONE launch at up to 64 blocks, every block re-deriving all chunks' counts itself
+//  instead of reading the table of a first launch: correct, bit-identical - and 62.7 us against 4.7 + 6.3, because the walk over the 47
+//  chunks is 47 dependent L2 round trips per block.)
 // Small token counts (one or two clips: the reference's serving shape, scripts/test_final.py:357): count + place in ONE launch of one
 // 1024-thread workgroup - at 1504 tokens the two multi-block kernels above are two ~4.6-us launch floors for 6 blocks of work.
 // Same result, bit for bit (stable: ascending token order inside a group).
