@@ -582,7 +582,6 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
         GemmArgs g;
         g.A = a.xt; g.a_plane = d.xt_plane; g.lda = a.Ci; g.B = a.wp; g.b_plane = a.wp_plane; g.ldb = a.Ci_pad;
         g.M = a.B * a.T_out; g.N = a.Co; g.K = d.ntaps * a.Ci; g.nseg = 3; g.ngroups = a.B;
-        g.group_off = reinterpret_cast<const int*>(a.xt);        // uniform groups: only its non-nullness is looked at (group_rows > 0)
         g.group_rows = a.T_out; g.T = a.T_out; g.epi = EPI_F32_CT; g.bias = a.bias; g.out32 = a.out; g.res32 = a.res;
         g.conv_ci = a.Ci; g.conv_dil = d.dil; g.conv_agrp = d.xt_Tp; g.conv_arow0 = XT_HEAD - a.pad; g.conv_btap = (int64_t)a.Co * a.Ci_pad;
         g.prof_class = 2;

@@ -2109,6 +2109,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return VB_OK;
     if (a.N % 4 || a.K % 8 || a.lda % 8 || a.ldb % 8) VB_FAIL(VB_E_INVALID, "gemm: N%%4, K%%8, lda%%8, ldb%%8 must be 0 (N=%d K=%d)", a.N, a.K);
     if (a.nseg != 1 && a.nseg != 3) VB_FAIL(VB_E_INVALID, "gemm: nseg must be 1 or 3");
+    // "row-range groups": the groups partition the rows (device array of offsets, or uniform groups of group_rows rows each); otherwise
+    // ngroups > 1 means the same rows against several operands (grid z)
+    const bool row_groups = a.group_off != nullptr || a.group_rows > 0;
     GemmDev d;
     d.A = a.A; d.a_plane = a.a_plane; d.lda = a.lda; d.a_rows = a.a_rows; d.a_koff_group = a.a_koff_group;
     d.B = a.B; d.b_plane = a.b_plane; d.ldb = a.ldb; d.b_group_stride = a.b_group_stride;
@@ -2121,7 +2124,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.conv_ci = a.conv_ci; d.conv_ktap = 0; d.conv_dil = a.conv_dil; d.conv_agrp = a.conv_agrp; d.conv_arow0 = a.conv_arow0; d.conv_btap = a.conv_btap;
     d.res32 = a.res32;
     if (a.conv_ci > 0) {
-        if (a.epi != EPI_F32_CT || !a.group_off || a.group_rows <= 0 || a.conv_ci % 64 || a.K % a.conv_ci || a.a_rows || a.group_rows != (a.T > 0 ? a.T : 1))
+        if (a.epi != EPI_F32_CT || a.group_rows <= 0 || a.conv_ci % 64 || a.K % a.conv_ci || a.a_rows || a.group_rows != (a.T > 0 ? a.T : 1))
             VB_FAIL(VB_E_INVALID, "gemm: conv mode needs EPI_F32_CT, uniform groups of T rows, Ci %% 64 == 0");
         d.conv_ktap = a.conv_ci / 64;
     }
@@ -2131,7 +2134,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.rT = 1.0f / (float)d.T; d.rhd = 1.0f / (float)d.hd; d.rD = 1.0f / (float)d.D;
     if (a.M >= (1 << 21) || (int64_t)a.N * (a.ngroups > 0 ? a.ngroups : 1) >= (1 << 21)) VB_FAIL(VB_E_INVALID, "gemm: index ranges exceed fdiv()");
     d.trace = g_gemm_trace; d.abl = vb_tune().gemm_ablate; d.no_vt16 = vb_tune().qkv_vt16_off ? 1 : 0;
-    const double gz_ = (a.group_off || a.ngroups <= 1) ? 1.0 : (double)a.ngroups;        // groups that share the row range multiply the work
+    const double gz_ = (row_groups || a.ngroups <= 1) ? 1.0 : (double)a.ngroups;        // groups that share the row range multiply the work
     const double npl_ = a.nseg == 3 ? 2.0 : 1.0, MN_ = (double)a.M * a.N * gz_;
     double ob_;                                                                         // result (+ read-modify) bytes of the epilogue
     switch (a.epi) {
@@ -2152,17 +2155,17 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const int forced = vb_tune().gemm_tile;
         if (forced >= 0) {
             cfg = forced == 22 ? 0 : forced;
-            if (cfg == 23 && !(a.epi == EPI_RESID_GATE && !a.group_off && a.ngroups <= 1 && a.N % 192 == 0)) cfg = 0;    // 23 serves the plain gated-residual GEMM
+            if (cfg == 23 && !(a.epi == EPI_RESID_GATE && !row_groups && a.ngroups <= 1 && a.N % 192 == 0)) cfg = 0;    // 23 serves the plain gated-residual GEMM
         } else {
             // measured (tools/gemm_tilecfg.py): the 192x192 kernel wins when its tiles fit one round of the 256 CUs
             // (12032 x 768: 252 tiles); with several rounds per CU the 128x128 kernel (two co-resident workgroups
             // overlapping each other's epilogue) is as fast or faster.
-            const int gz = a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
-            const int64_t rt = a.group_off ? (cdiv(a.M, 192) + a.ngroups) : cdiv(a.M, 192);
+            const int gz = row_groups ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
+            const int64_t rt = row_groups ? (cdiv(a.M, 192) + a.ngroups) : cdiv(a.M, 192);
             const int64_t t33 = rt * cdiv(a.N, 192) * gz;
-            const int64_t t22 = (a.group_off ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
+            const int64_t t22 = (row_groups ? (cdiv(a.M, BM) + a.ngroups) : (int64_t)cdiv(a.M, BM)) * cdiv(a.N, BN) * gz;
             const int64_t t23 = (int64_t)cdiv(a.M, BM) * (a.N / 192);
-            if (a.epi == EPI_RESID_GATE && !a.group_off && gz == 1 && a.N % 192 == 0 && t22 > 512 && t23 <= 512 && vb_tune().wide_resid) cfg = 23;
+            if (a.epi == EPI_RESID_GATE && !row_groups && gz == 1 && a.N % 192 == 0 && t22 > 512 && t23 <= 512 && vb_tune().wide_resid) cfg = 23;
             // (K >= 384 since round 3: at one clip the band experts' K = 192 first product took the 192 x 192 one-per-CU kernel - three
             //  k-iterations under a 24-KB-per-stage ring, 18 us - where 128 x 128 tiles run ~8: one 20 s clip 40.2 -> 38.2 ms)
             else if (t33 <= 256 + 16 && t22 > 320 && !a.rows_out && a.K >= vb_tune().big_tile_min_k) cfg = 33;      // (row-scatter epilogues measured slower on it)
@@ -2184,8 +2187,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const bool epi_ok = a.epi == EPI_PLANES || a.epi == EPI_F32 || a.epi == EPI_QKV_ROPE || a.epi == EPI_RESID_GATE ||
                             a.epi == EPI_SWIGLU || a.epi == EPI_SCATTER_F32 || a.epi == EPI_SCATTER_ADD_PLANES;
         if (epi_ok && a.K % 32 == 0 && p8 != 0 && vb_tune().gemm_tile < 0) {
-            const int gz = a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
-            const int64_t t88 = (int64_t)(a.group_off ? (cdiv(a.M, 256) + a.ngroups) : cdiv(a.M, 256)) * cdiv(a.N, 256) * gz;
+            const int gz = row_groups ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
+            const int64_t t88 = (int64_t)(row_groups ? (cdiv(a.M, 256) + a.ngroups) : cdiv(a.M, 256)) * cdiv(a.N, 256) * gz;
             // measured (tools/gemm_p8_bench.py, profiles/r02_gemm_p8_microbench.txt): with one workgroup per CU nothing overlaps a
             // tile's epilogue, so the 8-wave kernel only wins where the mainloop outweighs the output traffic - the wide
             // projections (N >= 1024: QKV, routed w1/w3); the N = 768 / 640 launches stay on the two-per-CU 128 x 128 kernel
@@ -2204,25 +2207,27 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         cfg = (vb_tune().gemm_small == 11 && t22c < vb_tune().gemm_small_tiles) ? 11 : 0;
     }
     if (cfg == 23) {     // 128 x 192, two per CU, gated-residual epilogue (gemm_bf16_wide_resid_kernel)
-        if (a.epi != EPI_RESID_GATE || a.group_off || a.N % 192 || a.K % 64) VB_FAIL(VB_E_INVALID, "gemm: tile 23 serves the plain gated-residual GEMM only");
+        if (a.epi != EPI_RESID_GATE || row_groups || a.N % 192 || a.K % 64) VB_FAIL(VB_E_INVALID, "gemm: tile 23 serves the plain gated-residual GEMM only");
         d.n_tiles = a.N / 192;
         hipLaunchKernelGGL(gemm_bf16_wide_resid_kernel<3>, dim3(d.n_tiles * ((cdiv(a.M, BM) + 7) / 8 * 8)), dim3(NTHREADS), 0, st, d);
         VB_CHECK_LAUNCH();
         return VB_OK;
     }
     const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
-    int mt = a.group_off ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
+    int mt = row_groups ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
     d.grp_rows = 0; d.grp_tiles = 0; d.grp_xcd = 0;
+    if (a.group_rows > 0 && !a.group_off && !(!cfg || (cfg == 11 && a.conv_ci > 0)))
+        VB_FAIL(VB_E_INVALID, "gemm: uniform groups without an offset array run on the 128 x 128 kernel (or 64 x 64 in conv mode) only");
     if (a.conv_ci > 0 && ((cfg != 0 && cfg != 11) || a.K % 64)) VB_FAIL(VB_E_INVALID, "gemm: conv mode runs on the 128 x 128 / 64 x 64 DMA kernels (K %% 64 == 0)");
-    if ((!cfg || (cfg == 11 && a.conv_ci > 0)) && a.group_off && a.group_rows > 0 && a.K % 32 == 0) {      // uniform groups: 128 x 128 kernel; 64 x 64 in conv mode
+    if ((!cfg || (cfg == 11 && a.conv_ci > 0)) && a.group_rows > 0 && a.K % 32 == 0) {      // uniform groups: 128 x 128 kernel; 64 x 64 in conv mode
         d.grp_rows = a.group_rows; d.grp_tiles = cdiv(a.group_rows, bm);
         d.grp_xcd = (a.conv_ci == 0 && a.ngroups % 8 == 0 && !vb_tune().no_xcd_groups) ? 1 : 0;
         mt = d.grp_xcd ? a.ngroups * d.grp_tiles : (a.ngroups * d.grp_tiles + 7) / 8 * 8;
     }
-    dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, a.group_off ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
+    dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, row_groups ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
     d.ncc = 0; d.rpx = (mt + 7) / 8;
-    if (!cfg && !a.group_off) {       // VB_GEMM_NCHUNK=c (tuning, default off until measured in the pipeline): column chunking for wide N
+    if (!cfg && !row_groups) {       // VB_GEMM_NCHUNK=c (tuning, default off until measured in the pipeline): column chunking for wide N
         const int c = vb_tune().gemm_nchunk;
         if (c > 0 && d.n_tiles > c && d.n_tiles % c == 0) d.ncc = c;
     }

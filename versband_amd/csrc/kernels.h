@@ -28,7 +28,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int nseg = 1;                     // 1 = plain bf16, 3 = bf16x3 split precision
     int ngroups = 1; const int* group_off = nullptr;   // device [ngroups+1] slot offsets (null: one group [0,M))
-    int group_rows = 0;               // > 0 (with group_off): every group has exactly this many rows (group g = rows [g R, (g+1) R): per-clip
+    int group_rows = 0;               // > 0 (group_off optional then): every group has exactly this many rows (group g = rows [g R, (g+1) R): per-clip
                                       // operands) - the 128 x 128 kernel then keeps all tiles of a group on ONE XCD (group g -> XCD g % 8), so
                                       // a group's B operand is fetched into one L2 instead of all eight
     int c_noff_group = 0;             // output column offset per group
