@@ -80,7 +80,7 @@ struct VbTune {
     int conv_cfg = 0, conv_ablate = 0, attn_ablate = 0, attn_variant = -1;
     bool conv_direct_epi = false, gate_unfolded = false, stem_f32 = false, band_unfused = false, moe_unfused = false, score_fused = false, no_graph = false;
     int w2_pair = 1;
-    bool qkv_p16_off = false, no_xcd_groups = false, qkv_vt16_off = false;
+    bool qkv_p16_off = false, no_xcd_groups = false, qkv_vt16_off = false, rmsnorm_generic = false;
     int wide_resid = 1, big_tile_min_k = 384;
     bool proj_in_conv = false, conv_gemm_off = false, final_gemm = false;
 };

@@ -10,48 +10,101 @@
 // RMSNorm * w, then adaLN modulate, written as bf16 planes (feeds the MFMA GEMMs)
 //   RMSNorm  flag_large_dit_moe.py:52-77 ; modulate :80-81
 // ---------------------------------------------------------------------------
+// (round 3: the row stays in registers between the two passes - the second pass re-read it from L2 - and a wave walks TWO rows with all
+//  their loads issued up front; same arithmetic in the same order, bit-identical)
+template <int NQ>     // D = 256 * NQ (NQ float4 per lane and row); NQ = 0: generic D % 4 == 0 (re-reads the row)
 __global__ void __launch_bounds__(256) rmsnorm_mod_kernel(const float* __restrict__ h, const float* __restrict__ w,
                                                          const float* shift, const float* scale, int mod_ld, int rows, int D,
                                                          int T, float eps, Planes out) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma clang fp contract(off)      // both forms must round alike: no implicit fma
     const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* x = h + (int64_t)row * D;
-    float ss = 0.f;
-    for (int k = lane * 4; k < D; k += 256) {
-        float4 v = *reinterpret_cast<const float4*>(x + k);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    ss = wave_sum(ss);
-    const float r = rsqrtf(ss / (float)D + eps);
-    const int b = row / T;
-    for (int k = lane * 4; k < D; k += 256) {
-        float4 v = *reinterpret_cast<const float4*>(x + k);
-        float4 ww = *reinterpret_cast<const float4*>(w + k);
-        float o[4] = {v.x * r * ww.x, v.y * r * ww.y, v.z * r * ww.z, v.w * r * ww.w};
-        if (scale) {
-            float4 sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * mod_ld + k);
-            float4 sh = *reinterpret_cast<const float4*>(shift + (int64_t)b * mod_ld + k);
-            o[0] = o[0] * (1.f + sc.x) + sh.x; o[1] = o[1] * (1.f + sc.y) + sh.y;
-            o[2] = o[2] * (1.f + sc.z) + sh.z; o[3] = o[3] * (1.f + sc.w) + sh.w;
+    if constexpr (NQ == 0) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (row >= rows) return;
+        const float* x = h + (int64_t)row * D;
+        float ss = 0.f;
+        for (int k = lane * 4; k < D; k += 256) {
+            float4 v = *reinterpret_cast<const float4*>(x + k);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         }
-        bf16x4 hi;
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)D + eps);
+        const int b = row / T;
+        for (int k = lane * 4; k < D; k += 256) {
+            float4 v = *reinterpret_cast<const float4*>(x + k);
+            float4 ww = *reinterpret_cast<const float4*>(w + k);
+            float o[4] = {v.x * r * ww.x, v.y * r * ww.y, v.z * r * ww.z, v.w * r * ww.w};
+            if (scale) {
+                float4 sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * mod_ld + k);
+                float4 sh = *reinterpret_cast<const float4*>(shift + (int64_t)b * mod_ld + k);
+                o[0] = o[0] * (1.f + sc.x) + sh.x; o[1] = o[1] * (1.f + sc.y) + sh.y;
+                o[2] = o[2] * (1.f + sc.z) + sh.z; o[3] = o[3] * (1.f + sc.w) + sh.w;
+            }
+            bf16x4 hi;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hi[i] = f2bf(o[i]);
-        *reinterpret_cast<bf16x4*>(out.p + (int64_t)row * D + k) = hi;
-        if (out.np == 2) {
-            bf16x4 lo;
+            for (int i = 0; i < 4; ++i) hi[i] = f2bf(o[i]);
+            *reinterpret_cast<bf16x4*>(out.p + (int64_t)row * D + k) = hi;
+            if (out.np == 2) {
+                bf16x4 lo;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lo[i] = f2bf(o[i] - bf2f(hi[i]));
-            *reinterpret_cast<bf16x4*>(out.p + out.plane + (int64_t)row * D + k) = lo;
+                for (int i = 0; i < 4; ++i) lo[i] = f2bf(o[i] - bf2f(hi[i]));
+                *reinterpret_cast<bf16x4*>(out.p + out.plane + (int64_t)row * D + k) = lo;
+            }
+        }
+    } else {
+        const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+        if (row0 >= rows) return;
+        float4 v[2][NQ];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const float* x = h + (int64_t)min(row0 + rr, rows - 1) * D;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) v[rr][i] = *reinterpret_cast<const float4*>(x + lane * 4 + 256 * i);
+        }
+        float4 ww[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) ww[i] = *reinterpret_cast<const float4*>(w + lane * 4 + 256 * i);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = row0 + rr;
+            if (row >= rows) break;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) ss += v[rr][i].x * v[rr][i].x + v[rr][i].y * v[rr][i].y + v[rr][i].z * v[rr][i].z + v[rr][i].w * v[rr][i].w;
+            ss = wave_sum(ss);
+            const float r = rsqrtf(ss / (float)D + eps);
+            const int b = row / T;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int k = lane * 4 + 256 * i;
+                float o[4] = {v[rr][i].x * r * ww[i].x, v[rr][i].y * r * ww[i].y, v[rr][i].z * r * ww[i].z, v[rr][i].w * r * ww[i].w};
+                if (scale) {
+                    float4 sc = *reinterpret_cast<const float4*>(scale + (int64_t)b * mod_ld + k);
+                    float4 sh = *reinterpret_cast<const float4*>(shift + (int64_t)b * mod_ld + k);
+                    o[0] = o[0] * (1.f + sc.x) + sh.x; o[1] = o[1] * (1.f + sc.y) + sh.y;
+                    o[2] = o[2] * (1.f + sc.z) + sh.z; o[3] = o[3] * (1.f + sc.w) + sh.w;
+                }
+                bf16x4 hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hi[e] = f2bf(o[e]);
+                *reinterpret_cast<bf16x4*>(out.p + (int64_t)row * D + k) = hi;
+                if (out.np == 2) {
+                    bf16x4 lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lo[e] = f2bf(o[e] - bf2f(hi[e]));
+                    *reinterpret_cast<bf16x4*>(out.p + out.plane + (int64_t)row * D + k) = lo;
+                }
+            }
         }
     }
 }
 int launch_rmsnorm_mod(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D,
                        int T, float eps, Planes out, hipStream_t st) {
     if (D % 4) VB_FAIL(VB_E_INVALID, "rmsnorm: D%%4");
-    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, w, shift, scale, mod_ld, rows, D, T > 0 ? T : 1,
-                       eps, out);
+    const int Tq = T > 0 ? T : 1;
+    if (D == 768 && !vb_tune().rmsnorm_generic) hipLaunchKernelGGL(rmsnorm_mod_kernel<3>, dim3(cdiv(rows, 8)), dim3(256), 0, st, h, w, shift, scale, mod_ld, rows, D, Tq, eps, out);
+    else if (D == 1024 && !vb_tune().rmsnorm_generic) hipLaunchKernelGGL(rmsnorm_mod_kernel<4>, dim3(cdiv(rows, 8)), dim3(256), 0, st, h, w, shift, scale, mod_ld, rows, D, Tq, eps, out);
+    else hipLaunchKernelGGL(rmsnorm_mod_kernel<0>, dim3(cdiv(rows, 4)), dim3(256), 0, st, h, w, shift, scale, mod_ld, rows, D, Tq, eps, out);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

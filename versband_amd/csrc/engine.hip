@@ -38,6 +38,7 @@ static void tune_load() {
     t.qkv_p16_off = getenv("VB_QKV_P16_OFF") != nullptr;
     t.no_xcd_groups = getenv("VB_NO_XCD_GROUPS") != nullptr;
     t.qkv_vt16_off = getenv("VB_QKV_VT16_OFF") != nullptr;
+    t.rmsnorm_generic = getenv("VB_RMSNORM_GENERIC") != nullptr;
     t.wide_resid = env_int("VB_WIDE_RESID", 1);
     t.big_tile_min_k = env_int("VB_BIG_TILE_MIN_K", 384);
     t.proj_in_conv = getenv("VB_PROJ_IN_CONV") != nullptr;
