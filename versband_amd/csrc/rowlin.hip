@@ -150,17 +150,25 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
     for (int id = threadIdx.x * 4; id < C * D; id += 1024) *reinterpret_cast<float4*>(wl + id) = *reinterpret_cast<const float4*>(W + id);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // a wave walks PAIRS of rows: every weight quad read from LDS serves both (the LDS reads, not the 240 FMAs per row, set the pace)
-    for (int row0 = (blockIdx.x * 4 + wave) * 2; row0 < rows; row0 += gridDim.x * 8) {
-        float4 x[2][NQ];
-        int bb[2], tt[2];
+    // a wave walks FOUR rows at a time: every weight quad read from LDS serves all of them (the LDS reads, not the 240 FMAs per row, set
+    // the pace) and their reduction chains interleave
+    constexpr int RW = 4;
+    for (int row0 = (blockIdx.x * 4 + wave) * RW; row0 < rows; row0 += gridDim.x * 4 * RW) {
+        float4 x[RW][NQ];
+        int bb[RW], tt[RW];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const int row = min(row0 + r, rows - 1);
             const float* xr = h + (int64_t)row * D;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) x[r][i] = *reinterpret_cast<const float4*>(xr + lane * 4 + 256 * i);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int row = min(row0 + r, rows - 1);
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) { x[r][i] = *reinterpret_cast<const float4*>(xr + lane * 4 + 256 * i); s += (x[r][i].x + x[r][i].y) + (x[r][i].z + x[r][i].w); }
+            for (int i = 0; i < NQ; ++i) s += (x[r][i].x + x[r][i].y) + (x[r][i].z + x[r][i].w);
             const float mean = wave_sum_dpp(s) / (float)D;
             float vs = 0.f;
 #pragma unroll
@@ -178,23 +186,31 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
                 x[r][i].z = x[r][i].z * rs * (1.f + a.z) + c.z; x[r][i].w = x[r][i].w * rs * (1.f + a.w) + c.w;
             }
         }
-        float res0 = 0.f, res1 = 0.f;
+        float res[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) res[r] = 0.f;
         for (int n = 0; n < C; ++n) {
             const float* wr = wl + n * D + lane * 4;
-            float a0 = 0.f, a1 = 0.f;
+            float acc[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const float4 w = *reinterpret_cast<const float4*>(wr + 256 * i);
-                a0 += (x[0][i].x * w.x + x[0][i].y * w.y) + (x[0][i].z * w.z + x[0][i].w * w.w);
-                a1 += (x[1][i].x * w.x + x[1][i].y * w.y) + (x[1][i].z * w.z + x[1][i].w * w.w);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc[r] += (x[r][i].x * w.x + x[r][i].y * w.y) + (x[r][i].z * w.z + x[r][i].w * w.w);
             }
-            a0 = wave_sum_dpp(a0); a1 = wave_sum_dpp(a1);
-            if (lane == n) { res0 = a0; res1 = a1; }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const float t = wave_sum_dpp(acc[r]);
+                if (lane == n) res[r] = t;
+            }
         }
         if (lane < C) {
             const float bv = bias ? bias[lane] : 0.f;
-            out[((int64_t)bb[0] * C + lane) * T + tt[0]] = res0 + bv;
-            if (row0 + 1 < rows) out[((int64_t)bb[1] * C + lane) * T + tt[1]] = res1 + bv;
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                if (row0 + r < rows) out[((int64_t)bb[r] * C + lane) * T + tt[r]] = res[r] + bv;
         }
     }
 }
@@ -203,7 +219,7 @@ int launch_final_layer_fused(const float* h, const float* shift, const float* sc
                              int rows, int D, int T, int C, float eps, float* out, hipStream_t st) {
     if (!final_layer_fused_ok(D, C)) VB_FAIL(VB_E_INVALID, "final_layer_fused: D=%d C=%d unsupported", D, C);
     const size_t sh = (size_t)C * D * sizeof(float);
-    const int grid = min(cdiv(rows, 8), 512);
+    const int grid = min(cdiv(rows, 16), 512);
     static OnceFlags attr[4];
     auto go = [&](auto nq) {
         constexpr int NQ = decltype(nq)::value;
