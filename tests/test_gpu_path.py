@@ -491,6 +491,35 @@ def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T
     assert torch.equal(v1, v2), describe("P16 vs quad column layout of the QKV epilogue", v1, v2)
 
 
+@pytest.mark.parametrize("knob", ["VB_ROUTER_GENERIC", "VB_ROUTER_TPW=4", "VB_ROUTER_TPW=1", "VB_ROUTER_GENERIC=1 VB_ROUTER_TPW=4"])
+@pytest.mark.parametrize("E,prec,B,T", [(4, "bf16", 4, 752), (4, "bf16", 1, 752), (4, "split", 3, 700), (8, "split", 4, 752), (8, "split", 1, 300)])
+def test_router_forms_are_bit_identical(engines, monkeypatch, E, prec, B, T, knob):
+    """The router kernel runs two tokens per wave with the score columns per lane (10 = 80 keys x 8 heads / 64) and the expert count as
+    compile-time constants; the run-time-bound form (VB_ROUTER_GENERIC), four tokens per wave (VB_ROUTER_TPW=4, rounds 1-2) and one
+    (the small-launch form) must choose the same routes and gate weights to the bit: same additions in the same order."""
+    eng = engines[(E, prec)]
+    Lc = 80
+    inp = clip_batch(B, T, Lc)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2 * B,), 321, dtype=torch.int64)
+    v1, r1 = eng.forward(inp["x_latent"], t_idx, cond, seed=5, return_routes=True)
+    torch.cuda.synchronize()
+    v1, r1 = v1.clone(), r1.clone()
+    names = []
+    for kv in knob.split():
+        kname, _, kval = kv.partition("=")
+        monkeypatch.setenv(kname, kval or "1")
+        names.append(kname)
+    L.load().vb_tune_reload()
+    v2, r2 = eng.forward(inp["x_latent"], t_idx, cond, seed=5, return_routes=True)
+    torch.cuda.synchronize()
+    for kname in names:
+        monkeypatch.delenv(kname)
+    L.load().vb_tune_reload()
+    assert torch.isfinite(v1).all() and torch.equal(r1, r2)
+    assert torch.equal(v1, v2), describe("router forms", v1, v2)
+
+
 @needs_experiments
 @pytest.mark.parametrize("E,B,T", [(4, 4, 752), (4, 6, 500), (8, 4, 752)])
 def test_fused_score_router_matches_two_launches(ctx, sds, engines, monkeypatch, E, B, T):

@@ -358,7 +358,7 @@ int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n
     return VB_OK;
 }
 
-template <int PP, bool SC, int RT_TPW = RT_TPW_MAX>
+template <int PP, bool SC, int RT_TPW = RT_TPW_MAX, int KPL = 16, int EE = 0>
 __global__ void __launch_bounds__(256) router_kernel(const RouterDev a) {
     // gate weights staged once per block (every wave re-reading E*D floats per token through L1/L2 was the kernel's
     // whole cost); a wave then walks RT_TPW tokens
@@ -369,22 +369,29 @@ __global__ void __launch_bounds__(256) router_kernel(const RouterDev a) {
     }
     const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RT_TPW;
     if (n0 >= a.N) return;
-    router_tokens<PP, SC, RT_TPW>(a, n0, a.N, SC ? a.sc + (int64_t)n0 * a.NS : nullptr, a.NS, rt_ws);
+    router_tokens<PP, SC, RT_TPW, KPL, EE>(a, n0, a.N, SC ? a.sc + (int64_t)n0 * a.NS : nullptr, a.NS, rt_ws);
 }
-template <int PP, bool SC, int TPW>
+template <int PP, bool SC, int TPW, int KPL = 16, int EE = 0>
 static void launch_router_v(dim3 grid, size_t lds, hipStream_t st, const RouterDev& a) {
-    hipLaunchKernelGGL((router_kernel<PP, SC, TPW>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((router_kernel<PP, SC, TPW, KPL, EE>), grid, dim3(256), lds, st, a);
 }
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
                   hipStream_t st, const float* sc, int NS, int Hh) {
     const int Bq = B > 0 ? B : 1;
-    // tokens per wave: 4 amortise the noise generator and the arg-max over a wave; a launch that would not even put one workgroup on
-    // every CU that way (one or two clips) takes one token per wave instead - the kernel is pure latency there (29 us at 1504 tokens)
+    // tokens per wave: TWO (round 3; rounds 1-2: four).  Two tokens side by side amortise the noise generator and the arg-max, keep the
+    // wave's registers at half of the four-token form and put twice the waves on a SIMD: same box, 12032 tokens 23.1 -> 20.0 us, whole
+    // runs +1.2 % (8 clips, two streams), +2.9 % (E = 8, 32 clips), +1.8 % (4 x 120 s).  A launch that would not even put one workgroup on
+    // every CU that way (one or two clips) takes one token per wave instead - the kernel is pure latency there (29 us at 1504 tokens).
+    // The shape of configs/vocal2music.yaml (80 caption keys x 8 heads = 10 score columns per lane, E = 4) runs with both as compile-time
+    // constants: 10 exponentials per token instead of 16 and - what matters - loads the compiler can hoist: under the run-time bound
+    // `i < NS / 64` every one of the token's ten 16-byte gate-weight loads sat behind its own branch, ten L2 latencies in a row
+    // (19.7 -> 15.2 us at 12032 tokens; VB_ROUTER_GENERIC: the run-time-bound form, same bits).  E = 8 keeps the run-time form: with
+    // 20 weight registers per score column the hoisted form needs 220 VGPRs = two waves per SIMD and measured 0.7 % behind it (32 clips).
     const int forced = vb_tune().router_tpw;                  // VB_ROUTER_TPW=1|2|4 (tuning)
     const bool small = forced ? forced == 1 : cdiv(N, 4 * RT_TPW_MAX) < 256;
-    const bool two = forced == 2 && 2 * E + 2 <= 32;
+    const bool two = forced ? forced == 2 && 2 * E + 2 <= 32 : 2 * E + 2 <= 32;
     const dim3 grid(cdiv(N, 4 * (small ? 1 : (two ? 2 : RT_TPW_MAX))));
     const int pp = 2 * E + 2 <= 16 ? 4 : (2 * E + 2 <= 32 ? 2 : 1);
     RouterDev a;
@@ -394,7 +401,12 @@ int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, 
     if (sc) {
         // folded caption gate: logits from attention scores + per-clip VW (see router_tokens)
         if (NS % 64 || NS > 1024 || Hh < 1 || Hh > 64 || (Hh & (Hh - 1))) VB_FAIL(VB_E_INVALID, "router: NS=%d heads=%d unsupported", NS, Hh);
-        if (small) launch_router_v<1, true, 1>(grid, 0, st, a);
+        const bool fixed = NS == 640 && !vb_tune().router_generic;
+        if (fixed && E == 4) {
+            if (small) launch_router_v<1, true, 1, 10, 4>(grid, 0, st, a);
+            else if (two) launch_router_v<2, true, 2, 10, 4>(grid, 0, st, a);
+            else launch_router_v<4, true, 4, 10, 4>(grid, 0, st, a);
+        } else if (small) launch_router_v<1, true, 1>(grid, 0, st, a);
         else if (two) launch_router_v<2, true, 2>(grid, 0, st, a);
         else if (pp == 4) launch_router_v<4, true, 4>(grid, 0, st, a);
         else if (pp == 2) launch_router_v<2, true, 4>(grid, 0, st, a);
@@ -405,6 +417,7 @@ int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, 
     if ((E * D) % 4 != 0 || (size_t)E * D * sizeof(float) > 64 * 1024) VB_FAIL(VB_E_INVALID, "router: E*D=%d unsupported", E * D);
     const size_t lds = (size_t)E * D * sizeof(float);
     if (small) launch_router_v<1, false, 1>(grid, lds, st, a);
+    else if (two) launch_router_v<2, false, 2>(grid, lds, st, a);
     else if (pp == 4) launch_router_v<4, false, 4>(grid, lds, st, a);
     else if (pp == 2) launch_router_v<2, false, 4>(grid, lds, st, a);
     else launch_router_v<1, false, 4>(grid, lds, st, a);

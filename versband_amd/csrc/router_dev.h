@@ -26,8 +26,8 @@ __device__ __forceinline__ float gumbel_draw(uint64_t seed, int64_t clip, int nf
 // Sum EE per-lane partials over the wave with a halving butterfly: exchanging with lane^32 a lane keeps half of the
 // values, with lane^16 a quarter, ...; the last value is then summed over the remaining lane bits.  Returns, on lane e,
 // the full sum of value e (EE + log2(64/EE) - 1 shuffles instead of 6*EE).
-template <int EE>
-__device__ __forceinline__ float reduce_logits(const float (&part)[16], int lane) {
+template <int EE, int PE>
+__device__ __forceinline__ float reduce_logits(const float (&part)[PE], int lane) {
     float v[EE];
 #pragma unroll
     for (int e = 0; e < EE; ++e) v[e] = part[e];
@@ -139,13 +139,18 @@ __device__ __forceinline__ void router_phase_b(const RouterDev& a, const int n0,
 // One wave, tokens n0 .. n0 + RT_TPW - 1 (n0 < N).  `N` bounds the tokens this call may touch (the launch's token count, or the end of
 // the caller's clip tile); rows of the score matrix are read from sc_row0 + (n - n0) * sc_ld (global memory or LDS: a flat pointer);
 // rt_ws = gate weights staged in LDS by the caller (SC = false only).
-template <int PP, bool SC, int RT_TPW>     // PP: tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, 2 when <= 32
+// KPL: score columns per lane (NS / 64) as a compile-time constant - 10 for 80 caption keys x 8 heads - or 16 = "any NS <= 1024, bound
+// checked at run time": the generic form holds 16 registers per token and runs 16 exponentials where 10 are live (same values, same order
+// of additions: the padding entries contribute exp(-inf) = 0, so both forms round alike).
+// EE: experts per gate as a compile-time constant (4 / 8), 0 = run-time a.E (<= 16).
+template <int PP, bool SC, int RT_TPW, int KPL = 16, int EE = 0>     // PP: tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, 2 when <= 32
 __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, const int N, const float* sc_row0, const int sc_ld,
                                               const float* rt_ws) {
     const Planes cq = a.cq; const float* __restrict__ Wg = a.Wg; const float* __restrict__ bg = a.bg; const float* __restrict__ la = a.la;
     const int la_rows = a.la_rows; const float* __restrict__ hl = a.hl; const int hl_ld = a.hl_ld;
     const float* __restrict__ g1 = a.g1; const float* __restrict__ g2 = a.g2; const float* __restrict__ g3 = a.g3;
-    const int T = a.T, D = a.D, E = a.E, B = a.B, block = a.block, NS = a.NS, Hh = a.Hh;
+    const int T = a.T, D = a.D, E = EE ? EE : a.E, B = a.B, block = a.block, NS = a.NS, Hh = a.Hh;
+    constexpr int PE = EE ? EE : 16;      // partial-logit registers per token
     int* ic = a.ic; int* ia = a.ia; float* mc = a.mc; float* ma = a.ma; float* lc_out = a.lc_out;
     uint64_t seed = a.seed; int64_t clip_base = a.clip_base; int nfe_base = a.nfe_base; const int* step = a.step;
     (void)D; (void)cq; (void)rt_ws; (void)NS; (void)Hh; (void)sc_row0; (void)sc_ld;
@@ -154,47 +159,47 @@ __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, 
     const int lane = threadIdx.x & 63;
     // phase A: the RT_TPW tokens' feature loads are issued together (token features = MoE cross-attention output, bf16
     // planes; Wg/bg already contain out_proj folded in), then E partial dot products per lane and token
-    float parts[RT_TPW][16];
+    float parts[RT_TPW][PE];
     if constexpr (SC) {
         // lane owns head (lane % Hh) and the keys lane/Hh + (64/Hh) i: columns lane + 64 i (coalesced)
-        const int kpl = NS >> 6;                       // columns per lane (<= 16)
-        float sv[RT_TPW][16];
+        const int kpl = KPL == 16 ? (NS >> 6) : KPL;   // columns per lane (<= 16)
+        float sv[RT_TPW][KPL];
 #pragma unroll
         for (int tok = 0; tok < RT_TPW; ++tok) {
             const float* srow = sc_row0 + (int64_t)(min(n0 + tok, N - 1) - n0) * sc_ld + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sv[tok][i] = i < kpl ? srow[64 * i] : -INFINITY;
+            for (int i = 0; i < KPL; ++i) sv[tok][i] = i < kpl ? srow[64 * i] : -INFINITY;
         }
 #pragma unroll
         for (int tok = 0; tok < RT_TPW; ++tok) {
             const int bclip = min(n0 + tok, N - 1) / T;
             float m = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) m = fmaxf(m, sv[tok][i]);
+            for (int i = 0; i < KPL; ++i) m = fmaxf(m, sv[tok][i]);
             for (int o = Hh; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             float l = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sv[tok][i] = i < kpl ? __expf(sv[tok][i] - m) : 0.f; l += sv[tok][i]; }
+            for (int i = 0; i < KPL; ++i) { sv[tok][i] = i < kpl ? __expf(sv[tok][i] - m) : 0.f; l += sv[tok][i]; }
             for (int o = Hh; o < 64; o <<= 1) l += __shfl_xor(l, o, 64);
             const float inv = 1.f / l;
             const float* vwb = Wg + ((int64_t)bclip * NS + lane) * E;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) parts[tok][e] = 0.f;
+            for (int e = 0; e < PE; ++e) parts[tok][e] = 0.f;
             if (E == 4) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
+                for (int i = 0; i < KPL; ++i)
                     if (i < kpl) {
                         const float4 w = *reinterpret_cast<const float4*>(vwb + (int64_t)64 * i * 4);
                         acc.x += sv[tok][i] * w.x; acc.y += sv[tok][i] * w.y; acc.z += sv[tok][i] * w.z; acc.w += sv[tok][i] * w.w;
                     }
                 parts[tok][0] = acc.x * inv; parts[tok][1] = acc.y * inv; parts[tok][2] = acc.z * inv; parts[tok][3] = acc.w * inv;
-            } else if (E == 8) {
+            } else if (PE >= 8 && E == 8) {
                 // two 16-byte loads per (lane, key column) instead of eight 4-byte loads 32 B apart (8 experts, 48128 tokens: this loop
                 // was 469 us of a block evaluation, profiles/r02_c3_kernel_stats.csv)
                 float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
+                for (int i = 0; i < KPL; ++i)
                     if (i < kpl) {
                         const float4 w0 = *reinterpret_cast<const float4*>(vwb + (int64_t)64 * i * 8);
                         const float4 w1 = *reinterpret_cast<const float4*>(vwb + (int64_t)64 * i * 8 + 4);
@@ -202,14 +207,14 @@ __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, 
                         a1.x += sv[tok][i] * w1.x; a1.y += sv[tok][i] * w1.y; a1.z += sv[tok][i] * w1.z; a1.w += sv[tok][i] * w1.w;
                     }
                 parts[tok][0] = a0.x * inv; parts[tok][1] = a0.y * inv; parts[tok][2] = a0.z * inv; parts[tok][3] = a0.w * inv;
-                parts[tok][4] = a1.x * inv; parts[tok][5] = a1.y * inv; parts[tok][6] = a1.z * inv; parts[tok][7] = a1.w * inv;
+                if constexpr (PE >= 8) { parts[tok][4] = a1.x * inv; parts[tok][5] = a1.y * inv; parts[tok][6] = a1.z * inv; parts[tok][7] = a1.w * inv; }
             } else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                for (int e = 0; e < PE; ++e) {
                     float acc = 0.f;
                     if (e < E) {
 #pragma unroll
-                        for (int i = 0; i < 16; ++i)
+                        for (int i = 0; i < KPL; ++i)
                             if (i < kpl) acc += sv[tok][i] * vwb[(int64_t)64 * i * E + e];
                     }
                     parts[tok][e] = acc * inv;
@@ -240,7 +245,7 @@ __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, 
             }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < PE; ++e) {
             float acc[RT_TPW];
 #pragma unroll
             for (int tok = 0; tok < RT_TPW; ++tok) acc[tok] = 0.f;
@@ -267,13 +272,13 @@ __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, 
         float mylogit = 0.f;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
-            const float (&part)[16] = parts[t0 + j];
+            const float (&part)[PE] = parts[t0 + j];
             float logit_e = 0.f;      // valid on lanes [0,E)
-            if (E == 4) logit_e = reduce_logits<4>(part, lane);
-            else if (E == 8) logit_e = reduce_logits<8>(part, lane);
+            if (E == 4) { if constexpr (PE >= 4) logit_e = reduce_logits<4, PE>(part, lane); }
+            else if (E == 8) { if constexpr (PE >= 8) logit_e = reduce_logits<8, PE>(part, lane); }
             else {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                for (int e = 0; e < PE; ++e) {
                     if (e < E) {
                         const float r = wave_sum(part[e]);
                         if (lane == e) logit_e = r;
