@@ -464,7 +464,8 @@ def test_vae_wide_convs_as_gemm_match_the_conv_kernel(ctx, monkeypatch, B, T):
     assert rel_l2(m1, ref) < 2e-4, describe("VAE decode vs oracle", m1, ref)
 
 
-@pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_QKV_VT16_OFF", "VB_RMSNORM_GENERIC", "VB_NO_XCD_GROUPS", "VB_BIG_TILE_MIN_K=0", "VB_WIDE_RESID=0"])
+@pytest.mark.parametrize("knob", ["VB_QKV_P16_OFF", "VB_QKV_VT16_OFF", "VB_RMSNORM_GENERIC", "VB_NO_XCD_GROUPS", "VB_BIG_TILE_MIN_K=0", "VB_WIDE_RESID=0",
+                                  "VB_BAND_EPI_OLD"])
 @pytest.mark.parametrize("prec,B,T", [("bf16", 4, 752), ("split", 3, 700), ("bf16", 1, 752), ("bf16", 8, 752)])
 def test_qkv_p16_column_layout_is_bit_identical(engines, monkeypatch, prec, B, T, knob):
     """The QKV + RoPE GEMM fills its weight tile with permuted source rows so a lane's accumulator holds 16 CONSECUTIVE output columns

@@ -45,6 +45,7 @@ static void tune_load() {
     t.conv_gemm_off = getenv("VB_CONV_GEMM_OFF") != nullptr;
     t.final_gemm = getenv("VB_FINAL_GEMM") != nullptr;
     t.router_generic = getenv("VB_ROUTER_GENERIC") != nullptr;
+    t.band_epi_old = getenv("VB_BAND_EPI_OLD") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels

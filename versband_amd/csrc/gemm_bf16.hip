@@ -386,10 +386,14 @@ __device__ __forceinline__ void wave_epilogue_swiglu_p16(const GemmDev& p, int g
 // 4 consecutive tokens of one (head, d) row: the per-head V^T image the attention kernel reads, in 8-B pieces of 128-B runs.
 // Needs 64 * (BN + 4) * 4 bytes of LDS (BN * 68 * 4 for the transposed variant).
 // (NWC wave columns x 2 wave rows, NT threads: 2 x 2 / 256 for the 4-wave kernels, 4 x 2 / 512 for the 8-wave kernel)
-template <int EPI, int TM, int TN, int NWC = 2, int NT = NTHREADS>
+// HOIST (gated-residual epilogue of the fused band-expert kernel): the residual and gate values of a whole slab are requested BEFORE the
+// slab goes through LDS, not after the second barrier in two passes: one exposed HBM round trip per slab, overlapped with the staging,
+// instead of two behind it (same loads, same arithmetic, other issue order): band experts 63.2 -> 55.8 us at 12032 tokens (same box).
+template <int EPI, int TM, int TN, int NWC = 2, int NT = NTHREADS, bool HOIST = false>
 __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 (&acc)[TM][TN], float* stg, int row0, int rows_end,
                                                 int n0, int tid, int wr, int wc, int frow, int fk) {
     static_assert(NT == 128 * NWC, "two wave rows of NWC waves");
+    static_assert(!HOIST || EPI == EPI_RESID_GATE, "hoisted loads: gated-residual epilogue only");
     constexpr int BNB = NWC * 32 * TN;
     constexpr int PITCH = BNB + 4;               // floats; +4 keeps the 16-B column writes of 8 consecutive rows on distinct banks
     constexpr int QPR = BNB / 4;                 // quads per row
@@ -398,6 +402,18 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
     if constexpr (EPI == EPI_QKV_ROPE) vsec = n0 >= 2 * p.D && (p.D % BNB) == 0 && (p.T & 3) == 0 && (p.Tpad & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        EpiPre preH[HOIST ? QPT : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int k = 0; k < QPT; ++k) {
+                const int idx = tid + k * NT;
+                const int lr = idx / QPR, cq = idx - lr * QPR;
+                int slot = row0 + (lr >> 5) * 32 * TM + i * 32 + (lr & 31);
+                int n = n0 + cq * 4;
+                if (slot >= rows_end || n >= p.N) { slot = row0; n = n0; }      // (clamped, not branched: the stores below skip it)
+                epi_load<EPI>(p, g, slot, slot, n, preH[k]);
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): own LDS reads done (loop fragments / previous slab)
         __builtin_amdgcn_s_barrier();
         if constexpr (EPI == EPI_QKV_ROPE) {
@@ -475,7 +491,8 @@ __device__ __forceinline__ void staged_epilogue(const GemmDev& p, int g, f32x16 
                 if constexpr (EPI == EPI_SWIGLU) {
                     if (p.row_scale2) scale_[k] = (slot < p.scale_split ? p.row_scale : p.row_scale2)[p.a_rows[slot]];
                 }
-                epi_load<EPI>(p, g, slot, tok_[k], n, pre[k]);
+                if constexpr (HOIST) pre[k] = preH[kb + kk];
+                else epi_load<EPI>(p, g, slot, tok_[k], n, pre[k]);
             }
         }
 #pragma unroll
@@ -1103,6 +1120,7 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2
         }
     }
     // epilogue (EPI_RESID_GATE): out32[m][n..n+15] = fmaf(gate[clip(m)][n..], v, out32[m][n..]); loads of a row slab first, then the stores
+    // (round 3, measured and dropped: both row slabs' residual values requested together - 248 VGPRs, 38.4 against 36.6 us)
     {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -1726,6 +1744,7 @@ struct BandDev {
 };
 #define BF_BM 192
 #define BF_BAND 192
+template <bool HOIST>      // HOIST: see staged_epilogue (VB_BAND_EPI_OLD=1 selects the two-pass form)
 __global__ void __launch_bounds__(NTHREADS) band_ffn_kernel(const BandDev p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bl[];
     constexpr int HCH = BF_BM * 128;              // bytes of the [192 x 64] bf16 hidden chunk
@@ -1896,7 +1915,7 @@ __global__ void __launch_bounds__(NTHREADS) band_ffn_kernel(const BandDev p) {
     // gated residual: h[:, band e] += gate * z   (same epilogue as the unfused w2 GEMM; LDS is free now)
     // (round 3: the same epilogue straight from the accumulators in the P16 column layout - no LDS slab, no epilogue barriers - measured
     //  62.9 against 63.5 us: the 74 MB read-modify-write of all 252 workgroups at once is an HBM burst, not an instruction-issue problem)
-    staged_epilogue<EPI_RESID_GATE, 3, 3>(p.ep, e, acc2, reinterpret_cast<float*>(bl), row0, rows_end, 0, tid, wr, wc, frow, fk);
+    staged_epilogue<EPI_RESID_GATE, 3, 3, 2, NTHREADS, HOIST>(p.ep, e, acc2, reinterpret_cast<float*>(bl), row0, rows_end, 0, tid, wr, wc, frow, fk);
     if (p.ep.trace && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         unsigned long long* tr = p.ep.trace + (size_t)blockIdx.x * 4;
@@ -2096,10 +2115,14 @@ int launch_band_ffn(const BandFfnArgs& a, hipStream_t st) {
     const int nblk = cdiv(row_tiles, per8) * 8;
     constexpr size_t lds = (size_t)BF_BM * 128 + 8 * 16384;   // hidden chunk (24 KB) + 8 ring slots of 16 KB = 152 KB
     static OnceFlags attr;
-    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(band_ffn_kernel), (int)lds);
+    static OnceFlags attr_old;
+    const bool hoist = !vb_tune().band_epi_old;
+    if (hoist) vb_set_max_lds_once(attr, reinterpret_cast<const void*>(band_ffn_kernel<true>), (int)lds);
+    else vb_set_max_lds_once(attr_old, reinterpret_cast<const void*>(band_ffn_kernel<false>), (int)lds);
     ProfScope prof(0, 2.0 * a.M * a.E * ((double)2 * a.H * a.band + (double)a.band * a.H),
                    (double)a.M * a.E * a.band * (2.0 + 8.0) + (double)a.E * 3.0 * a.H * a.band * 2.0, st);
-    hipLaunchKernelGGL(band_ffn_kernel, dim3(nblk), dim3(NTHREADS), lds, st, d);
+    if (hoist) hipLaunchKernelGGL(band_ffn_kernel<true>, dim3(nblk), dim3(NTHREADS), lds, st, d);
+    else hipLaunchKernelGGL(band_ffn_kernel<false>, dim3(nblk), dim3(NTHREADS), lds, st, d);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
