@@ -46,6 +46,7 @@ struct GemmDev {
     const float* rope_cos; const float* rope_sin; int H, hd, Tpad, D;
     float rT, rhd, rD;              // reciprocals for fdiv(): the epilogues decompose row -> (clip, t) and column -> (head, d)
     int no_vt16;                    // QKV P16: keep the V third on the row-per-lane layout (VB_QKV_VT16_OFF: bit-identity switch)
+    int epi_old;                    // gated-residual staged epilogue: request the residual after the staging, as rounds 1-3a did (VB_BAND_EPI_OLD)
     unsigned long long* trace;      // tuning only (vbdbg_gemm_trace): per block {t_start, t_loop_end, t_end, hw ids}
     int abl;                        // tuning only (VB_GEMM_ABLATE): 6 = QKV without the V^T stores, 7 = without the q/k stores, 8 = without the RoPE table loads
 };
@@ -1352,6 +1353,12 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
     }
 
     if constexpr (EPI == EPI_F32) { if (p.trace) t_loop = __builtin_amdgcn_s_memtime(); }
+    // gated residual on the 192 x 192 and 64 x 64 tiles (out-proj / unfused band w2 at 32 clips, long form, one or two clips): residual loads
+    // requested before the staging, like the fused band-expert kernel (see staged_epilogue HOIST)
+    if constexpr (EPI == EPI_RESID_GATE && ((TM == 3 && TN == 3) || (TM == 1 && TN == 1))) {
+        if (!p.epi_old) staged_epilogue<EPI, TM, TN, 2, NTHREADS, true>(p, g, acc, reinterpret_cast<float*>(ldsb), row0, rows_end, n0, tid, wr, wc, frow, fk);
+        else staged_epilogue<EPI, TM, TN>(p, g, acc, reinterpret_cast<float*>(ldsb), row0, rows_end, n0, tid, wr, wc, frow, fk);
+    } else
     staged_epilogue<EPI, TM, TN>(p, g, acc, reinterpret_cast<float*>(ldsb), row0, rows_end, n0, tid, wr, wc, frow, fk);
     if constexpr (EPI == EPI_F32) {
         if (p.trace && tid == 0) {
@@ -2156,7 +2163,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     d.Tpad = a.Tpad; d.D = a.D > 0 ? a.D : 1;
     d.rT = 1.0f / (float)d.T; d.rhd = 1.0f / (float)d.hd; d.rD = 1.0f / (float)d.D;
     if (a.M >= (1 << 21) || (int64_t)a.N * (a.ngroups > 0 ? a.ngroups : 1) >= (1 << 21)) VB_FAIL(VB_E_INVALID, "gemm: index ranges exceed fdiv()");
-    d.trace = g_gemm_trace; d.abl = vb_tune().gemm_ablate; d.no_vt16 = vb_tune().qkv_vt16_off ? 1 : 0;
+    d.trace = g_gemm_trace; d.abl = vb_tune().gemm_ablate; d.no_vt16 = vb_tune().qkv_vt16_off ? 1 : 0; d.epi_old = vb_tune().band_epi_old ? 1 : 0;
     const double gz_ = (row_groups || a.ngroups <= 1) ? 1.0 : (double)a.ngroups;        // groups that share the row range multiply the work
     const double npl_ = a.nseg == 3 ? 2.0 : 1.0, MN_ = (double)a.M * a.N * gz_;
     double ob_;                                                                         // result (+ read-modify) bytes of the epilogue
