@@ -32,8 +32,7 @@ static void tune_load() {
     t.gemm_tile = env_int("VB_GEMM_TILE", -1);
     t.conv_cfg = env_int("VB_CONV_CFG", 0);
     t.conv_direct_epi = getenv("VB_CONV_DIRECT_EPI") != nullptr;
-    t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
-    t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr; t.moe_unfused = getenv("VB_MOE_UNFUSED") != nullptr;
+    t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr;
     t.w2_pair = env_int("VB_W2_PAIR", 1);
     t.qkv_p16_off = getenv("VB_QKV_P16_OFF") != nullptr;
     t.no_xcd_groups = getenv("VB_NO_XCD_GROUPS") != nullptr;
@@ -55,6 +54,8 @@ static void tune_load() {
     t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
     t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
     t.score_fused = getenv("VB_SCORE_FUSED") != nullptr;
+    // round-2 A/B switches no test flips any more: the caption gate without the fold, the once-per-clip stem convolutions in exact fp32
+    t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
 #endif
     g_tune = t;
     g_tune_gen.fetch_add(1, std::memory_order_relaxed);

@@ -146,14 +146,10 @@ __device__ __forceinline__ void router_phase_b(const RouterDev& a, const int n0,
 template <int PP, bool SC, int RT_TPW, int KPL = 16, int EE = 0>     // PP: tokens laid side by side in a wave in phase B: 4 when 2E+2 <= 16, 2 when <= 32
 __device__ __forceinline__ void router_tokens(const RouterDev& a, const int n0, const int N, const float* sc_row0, const int sc_ld,
                                               const float* rt_ws) {
-    const Planes cq = a.cq; const float* __restrict__ Wg = a.Wg; const float* __restrict__ bg = a.bg; const float* __restrict__ la = a.la;
-    const int la_rows = a.la_rows; const float* __restrict__ hl = a.hl; const int hl_ld = a.hl_ld;
-    const float* __restrict__ g1 = a.g1; const float* __restrict__ g2 = a.g2; const float* __restrict__ g3 = a.g3;
-    const int T = a.T, D = a.D, E = EE ? EE : a.E, B = a.B, block = a.block, NS = a.NS, Hh = a.Hh;
+    const Planes cq = a.cq; const float* __restrict__ Wg = a.Wg;
+    const int T = a.T, D = a.D, E = EE ? EE : a.E, NS = a.NS, Hh = a.Hh;
     constexpr int PE = EE ? EE : 16;      // partial-logit registers per token
-    int* ic = a.ic; int* ia = a.ia; float* mc = a.mc; float* ma = a.ma; float* lc_out = a.lc_out;
-    uint64_t seed = a.seed; int64_t clip_base = a.clip_base; int nfe_base = a.nfe_base; const int* step = a.step;
-    (void)D; (void)cq; (void)rt_ws; (void)NS; (void)Hh; (void)sc_row0; (void)sc_ld;
+    (void)D; (void)cq; (void)rt_ws; (void)NS; (void)Hh; (void)sc_row0; (void)sc_ld; (void)T; (void)Wg;
     // gate weights staged once per block (every wave re-reading E*D floats per token through L1/L2 was the kernel's
     // whole cost); a wave then walks RT_TPW tokens
     const int lane = threadIdx.x & 63;
