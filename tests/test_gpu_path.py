@@ -330,16 +330,22 @@ def test_eight_wave_gemm_matches_four_wave_kernels(engines, monkeypatch):
         eng = engines[(4, prec)]
         cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
         outs = []
-        for p8 in ("0", "1"):
-            monkeypatch.setenv("VB_GEMM_P8", p8)
+        # "1+p16": the 8-wave kernel with the P16 column layout on the QKV + RoPE (epilogue 2) and SwiGLU (4) launches (prepared at the end
+        # of round 3 for the first A/B of round 4, tools/gpu_ab_p8_p16.sh)
+        for p8 in ("0", "1", "1+p16"):
+            monkeypatch.setenv("VB_GEMM_P8", p8[0])
+            if p8.endswith("p16"):
+                monkeypatch.setenv("VB_GEMM_P8_P16", str((1 << 2) | (1 << 4)))
             L.load().vb_tune_reload()
             v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
             torch.cuda.synchronize()
             outs.append((v.clone(), r.clone()))
         monkeypatch.delenv("VB_GEMM_P8")
+        monkeypatch.delenv("VB_GEMM_P8_P16")
         L.load().vb_tune_reload()
-        assert torch.equal(outs[0][1], outs[1][1]), prec
-        assert torch.equal(outs[0][0], outs[1][0]), describe(f"8-wave vs 4-wave GEMM ({prec})", outs[1][0], outs[0][0])
+        for k in (1, 2):
+            assert torch.equal(outs[0][1], outs[k][1]), (prec, k)
+            assert torch.equal(outs[0][0], outs[k][0]), describe(f"8-wave vs 4-wave GEMM ({prec}, form {k})", outs[k][0], outs[0][0])
 
 
 @pytest.mark.parametrize("E,B,T", [(4, 2, 752), (8, 3, 752), (8, 4, 700)])

@@ -76,7 +76,7 @@ extern thread_local char g_vb_err[512];
 // knob at run time call vb_tune_reload() (exported, not part of the product ABI) after changing the environment.
 struct VbTune {
     float attn_defer_thr = 8.f;
-    int router_tpw = 0, gemm_small = 11, gemm_small_tiles = 200, gemm_tile = -1, gemm_variant = 1, gemm_ablate = 0, gemm_nchunk = 0, gemm_p8 = -1, gemm_p8_mask = 0, gemm_p8_direct = 0;
+    int router_tpw = 0, gemm_small = 11, gemm_small_tiles = 200, gemm_tile = -1, gemm_variant = 1, gemm_ablate = 0, gemm_nchunk = 0, gemm_p8 = -1, gemm_p8_mask = 0, gemm_p8_direct = 0, gemm_p8_p16 = 0;
     int conv_cfg = 0, conv_ablate = 0, attn_ablate = 0, attn_variant = -1;
     bool conv_direct_epi = false, gate_unfolded = false, stem_f32 = false, band_unfused = false, score_fused = false, no_graph = false;
     int w2_pair = 1;

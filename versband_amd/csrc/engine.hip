@@ -50,7 +50,7 @@ static void tune_load() {
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
     t.gemm_variant = env_int("VB_GEMM_VARIANT", 1); t.gemm_ablate = env_int("VB_GEMM_ABLATE", 0);
     t.gemm_nchunk = env_int("VB_GEMM_NCHUNK", 0); t.gemm_p8 = env_int("VB_GEMM_P8", -1);
-    t.gemm_p8_mask = env_int("VB_GEMM_P8_MASK", 0); t.gemm_p8_direct = env_int("VB_GEMM_P8_DIRECT", 0);
+    t.gemm_p8_mask = env_int("VB_GEMM_P8_MASK", 0); t.gemm_p8_direct = env_int("VB_GEMM_P8_DIRECT", 0); t.gemm_p8_p16 = env_int("VB_GEMM_P8_P16", 0);
     t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
     t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
     t.score_fused = getenv("VB_SCORE_FUSED") != nullptr;

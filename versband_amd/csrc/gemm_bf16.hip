@@ -1454,7 +1454,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_p8_kernel(const GemmDev p) {
             if (slot >= rows_end) slot = row0;
             const int arow = p.a_rows ? p.a_rows[slot] : slot;
             asrc[i] = p.A + (int64_t)arow * p.lda + g * p.a_koff_group + c * 8;
-            int nrow = n0 + r;
+            int nrow = n0 + (STG == 2 ? p16_src_row(r) : r);       // STG = 2: P16 column layout (16 consecutive output columns per lane)
             if (nrow >= p.N) nrow = 0;
             bsrc[i] = p.B + g * p.b_group_stride + (int64_t)nrow * p.ldb + c * 8;
         }
@@ -1590,7 +1590,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_p8_kernel(const GemmDev p) {
             if (sink == 12345.678f) p.out32[0] = sink;
             return;
         }
-        if constexpr (STG) staged_epilogue<EPI, 4, 2, 4, 512>(p, g, acc, reinterpret_cast<float*>(ldsp), row0, rows_end, n0, tid, wr, wc, frow, fk);
+        if constexpr (STG == 2) {
+            // round 3 (prepared, NOT yet measured): the P16 epilogues of the 4-wave kernels on the 256 x 256 tile - the quad-layout epilogue
+            // was what this kernel lost on in round 2 (DESIGN 5.0 "open", item 4); the V third keeps the row-per-lane stores
+            static_assert(EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU, "P16 epilogues exist for QKV + RoPE and SwiGLU");
+            if constexpr (EPI == EPI_QKV_ROPE) wave_epilogue_qkv_p16<4, 2>(p, acc, row0 + wr * 128, rows_end, n0 + wc * 64, frow, fk);
+            else wave_epilogue_swiglu_p16<4, 2>(p, g, acc, row0 + wr * 128, rows_end, n0 + wc * 64, frow, fk);
+        }
+        else if constexpr (STG) staged_epilogue<EPI, 4, 2, 4, 512>(p, g, acc, reinterpret_cast<float*>(ldsp), row0, rows_end, n0, tid, wr, wc, frow, fk);
         else wave_epilogue<EPI, 4, 2>(p, g, acc, row0 + wr * 128, rows_end, n0 + wc * 64, frow, fk);
         return;
     }
@@ -1658,6 +1665,12 @@ static void launch_p8(const GemmDev& d, dim3 grid, hipStream_t st, int variant) 
         if (variant == 15) { launch_p8_v<EPI, 32, 5, 0, 5>(d, grid, st); return; }
     }
     if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU) {
+        // VB_GEMM_P8_P16: P16 column layout (needs the software-pipelined schedule, K % 64 == 0 and 16-byte aligned output rows, like the 4-wave form)
+        if ((vb_tune().gemm_p8_p16 & (1 << EPI)) && P8_DEFAULT_PP == 0 && d.K % 64 == 0 && d.N % 16 == 0 &&
+            (EPI == EPI_QKV_ROPE || (d.ldc % 8 == 0 && d.c_noff_group % 8 == 0))) {
+            launch_p8_v<EPI, P8_DEFAULT_BKT, P8_DEFAULT_NST, 0, 0, 2>(d, grid, st);
+            return;
+        }
         if (vb_tune().gemm_p8_direct & (1 << EPI)) { launch_p8_v<EPI, P8_DEFAULT_BKT, P8_DEFAULT_NST, P8_DEFAULT_PP, 0, 0>(d, grid, st); return; }
     }
     launch_p8_v<EPI, P8_DEFAULT_BKT, P8_DEFAULT_NST, P8_DEFAULT_PP>(d, grid, st);
