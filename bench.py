@@ -5,7 +5,8 @@ A "step" = one pass of the whole hot path over one batch of synthetic clips that
 resident in HBM: conditioning precompute -> Euler flow steps with CFG (2 network evaluations
 per step, batched) -> VAE decode -> full HiFi-GAN decode.
 
-  --workload c2 (default)  BASELINE configs[1]: batch 8 x 20 s clips, 50 flow steps, bf16 DiT + fp32-class VAE/vocoder
+  --workload c2 (default)  BASELINE configs[1]: batch 8 x 20 s clips, 50 flow steps, bf16 DiT + fp32 VAE/vocoder (`value`); the same passes with
+                           the bf16x3 VAE/vocoder are timed in a second region (`split`)
   --workload c3            BASELINE configs[2]: Band-MoE stress, num_experts = 8, batch 32 (48 128 token rows per CFG branch)
   --workload c5            BASELINE configs[4]: long-form, batch 4 x 120 s (T = 4500 latent frames in windows of 1500 tokens,
                            cross-faded) + VAE decode of the whole latent + halo'd chunked vocoding
@@ -42,7 +43,18 @@ CLASSES = {
     2: ("split-bf16 (bf16x3) MFMA implicit-GEMM conv1d (VAE + HiFi-GAN)", "mfma", MFMA_BF16_TF / 3.0),
     3: ("fused HiFi-GAN ResBlock pair (bf16x3 MFMA, intermediate in LDS)", "mfma|hbm", MFMA_BF16_TF / 3.0),
 }
-CLASS_KERNELS = {0: ("gemm_bf16", "band_ffn", "moe_ffn"), 1: ("attn_kernel",), 2: ("conv1d_",), 3: ("respair_",)}
+CLASSES_FP32 = {
+    2: ("fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM conv1d (VAE + HiFi-GAN)", "mfma", MFMA_F32_TF),
+    3: ("fused HiFi-GAN ResBlock pair (f32 MFMA, intermediate in LDS)", "mfma|hbm", MFMA_F32_TF),
+}
+CLASS_KERNELS = {0: ("gemm_bf16", "band_ffn", "moe_ffn", "moe_w2"), 1: ("attn_kernel",), 2: ("conv1d_",), 3: ("respair_",)}
+
+
+def classes_for(vocoder_precision):
+    c = dict(CLASSES)
+    if vocoder_precision == "fp32":
+        c.update(CLASSES_FP32)
+    return c
 
 _T0 = time.time()
 
@@ -89,44 +101,59 @@ def pmc_traffic(cls):
         return None, None
 
 
-def pmc_traffic_live(cls, timeout):
+def pmc_traffic_live(cls, timeout, vocoder_precision="fp32"):
     """HBM bytes per launch of a kernel class MEASURED IN THIS RUN: two child runs of this same command (one stream, one pass, no
     baseline legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes: the two counters do
     not fit the TCC's 4 slots together), counter unit = KB, FETCH_SIZE doubled for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md
-    prescribes.  Returns (bytes per launch | None, how)."""
+    prescribes.  Returns (bytes per launch | None, how, per-kernel table): the table lists every kernel of the pass with its launches
+    and its FETCH (doubled) / WRITE megabytes per launch - which launch over-fetches is read off it."""
     import csv
     import glob
+    import re
     import shutil
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", None
     tot, n, t0 = 0.0, 0, time.time()
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
+    perk = {}
     for ctr, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="vb_pmc_")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
-               "--streams", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-isolated", "--no-parity-check", "--no-pmc"]
+               "--streams", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-isolated", "--no-parity-check", "--no-pmc",
+               "--vocoder-precision", vocoder_precision]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=max(10.0, timeout - (time.time() - t0)), env=env, cwd="/tmp")
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not fs:
-                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {r.stderr[-200:]}", None
             kb, launches = 0.0, 0
             for row in csv.DictReader(open(fs[0])):
-                if row["Counter_Name"] == ctr and any(k in row["Kernel_Name"] for k in CLASS_KERNELS[cls]):
+                if row["Counter_Name"] != ctr:
+                    continue
+                kn = re.sub(r"^void ", "", row["Kernel_Name"].split("(")[0])[:72]
+                e = perk.setdefault(kn, {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+                e[ctr] += mult * float(row["Counter_Value"]) * 1024.0
+                if ctr == "FETCH_SIZE":
+                    e["launches"] += 1
+                if any(k in row["Kernel_Name"] for k in CLASS_KERNELS[cls]):
                     kb += float(row["Counter_Value"])
                     launches += 1
             tot += mult * kb * 1024.0
             n = max(n, launches)
         except subprocess.TimeoutExpired:
-            return None, f"rocprofv3 --pmc {ctr} pass timed out"
+            return None, f"rocprofv3 --pmc {ctr} pass timed out", None
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    table = [{"kernel": k, "launches": v["launches"], "class": next((c for c, pats in CLASS_KERNELS.items() if any(q in k for q in pats)), None),
+              "fetch_mb_per_launch": v["FETCH_SIZE"] / max(v["launches"], 1) / 1e6, "write_mb_per_launch": v["WRITE_SIZE"] / max(v["launches"], 1) / 1e6,
+              "total_gb": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) / 1e9}
+             for k, v in sorted(perk.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])) if v["launches"]][:40]
     return ((tot / n) if n else None), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
-                                       f"(--streams 1, one pass, {n} launches of the class; FETCH doubled per the gfx950 note)")
+                                       f"(--streams 1, one pass incl. its warmup passes, {n} launches of the class; FETCH doubled per the gfx950 note)"), table
 
 
 class Telemetry:
@@ -220,10 +247,11 @@ def parse():
     ap.add_argument("--seconds", type=float, default=None, help="clip length in seconds (default 20; 120 for c5)")
     ap.add_argument("--flow-steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
-    ap.add_argument("--vocoder-precision", default="split", choices=["split", "fp32"],
-                    help="VAE + vocoder arithmetic: 'split' = fp32 I/O, every product as bf16 hi/lo pairs on the bf16 MFMA pipe (bf16x3, <= 3e-5 of "
-                         "exact fp32; the default, priced against bf16 peak / 3); 'fp32' = the literal 'fp32 vocoder' of configs[1] on "
-                         "v_mfma_f32_32x32x2_f32 (157 TFLOP/s roof)")
+    ap.add_argument("--vocoder-precision", default="both", choices=["both", "fp32", "split"],
+                    help="VAE + vocoder arithmetic: 'fp32' = the literal 'fp32 vocoder' of configs[1] on v_mfma_f32_32x32x2_f32 (157 TFLOP/s roof); "
+                         "'split' = fp32 I/O, every product as bf16 hi/lo pairs on the bf16 MFMA pipe (bf16x3, <= 3e-5 of exact fp32; priced "
+                         "against bf16 peak / 3); 'both' (default) = the timed region runs with fp32 (`value`, configs[1] as written) and then a "
+                         "second timed region of the same K passes runs with split (`split` sub-object), each with its own oracle check")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (N = 1, default c2 command, "
                                                           "rocprofv3 on PATH) that measure roofline.traffic in this run; fall back to the committed summary")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
@@ -493,10 +521,10 @@ def main():
         dist.all_reduce(seen)                      # every rank reports in over the data-path backend (RCCL unless one-device test)
         assert int(seen.item()) == world
     log("weights ready; packing")
-    if args.vocoder_precision == "fp32":
-        for cls in (2, 3):
-            nm, bd, _ = CLASSES[cls]
-            CLASSES[cls] = (nm.replace("split-bf16 (bf16x3) MFMA", "fp32 MFMA (v_mfma_f32_32x32x2_f32)").replace("bf16x3 MFMA", "f32 MFMA"), bd, MFMA_F32_TF)
+    # primary = the precision `value` is measured in (configs[1] as written: fp32 VAE / vocoder); secondary = bf16x3, timed in its own region
+    prim = "fp32" if args.vocoder_precision == "both" else args.vocoder_precision
+    sec = "split" if args.vocoder_precision == "both" else None
+    CLS = classes_for(prim)
     ctx = Context(device)
     S = max(1, args.streams)
     B = args.batch
@@ -512,8 +540,10 @@ def main():
     def make_worker(nclips, clip_base, share=None):
         eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision, share=share)
         inp = clip_batch(nclips, T_lat, L_CTX, clip0=clip_base, seed=SEED)
-        return dict(eng=eng, vae=build_vae_decoder(ctx, sds[1], precision=args.vocoder_precision),
-                    voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=args.vocoder_precision),
+        nets2 = dict(vae=build_vae_decoder(ctx, sds[1], precision=sec), voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=sec),
+                     z0=None, mel0=None, kept={}, wav=None) if sec else None
+        return dict(eng=eng, vae=build_vae_decoder(ctx, sds[1], precision=prim),
+                    voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=prim), sec=nets2,
                     x0=inp["x_latent"].to(device), t5c=inp["t5_cond"].to(device), t5u=inp["t5_uncond"].to(device),
                     t5=torch.cat([inp["t5_cond"], inp["t5_uncond"]]).to(device), midi=inp["midi"].to(device),
                     beats=inp["beats"].to(device), stream=torch.cuda.Stream(device=device), clip_base=clip_base, wav=None, z0=None, mel0=None,
@@ -525,28 +555,30 @@ def main():
     for si in range(S):
         workers.append(make_worker(sizes[si], rank * B + sum(sizes[:si]), share=workers[0]["eng"] if workers else None))
 
-    def one_pass(w, k):
+    def one_pass(w, k, second=False):
+        n = w["sec"] if second else w          # the nets and the result slots of this precision
         if long:
             z = longform.sample_long(w["eng"], w["x0"], w["t5c"], w["t5u"], w["midi"], w["beats"], idx, dts, args.scale,
                                      window=dcfg.max_len, overlap=128, seed=SEED + k, clip_base=w["clip_base"])
-            mel = w["vae"].run(z)
-            w["wav"] = longform.vocode_chunked(w["voc"], mel, chunk=3000, halo=32)
+            mel = n["vae"].run(z)
+            n["wav"] = longform.vocode_chunked(n["voc"], mel, chunk=3000, halo=32)
         else:
             cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_lat, persistent=True)
             z = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + k, clip_base=w["clip_base"])
-            mel = w["vae"].run(z)
-            w["wav"] = w["voc"].run(mel)
+            mel = n["vae"].run(z)
+            n["wav"] = n["voc"].run(mel)
         if k == 0:
-            w["z0"], w["mel0"] = z[:1], mel[:1]
+            n["z0"], n["mel0"] = z[:1], mel[:1]
         if k in keep_passes:
             # latents / mels of this pass stay resident (a few MB) and are verified AFTER the timed region: every clip the fixture covers
-            # (global clips 0 and 4 = the first clip of each sub-batch) on the first pass, the first replay and the last pass
-            w["kept"][k] = (z, mel)
+            # (global clips 0, 4 and 7: the first clip of each sub-batch and the last row of the batch) on the first pass, the first replay
+            # and the last pass
+            n["kept"][k] = (z, mel)
 
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
     pinned = {}
 
-    def run_worker(w, ks):
+    def run_worker(w, ks, second=False):
         torch.cuda.set_device(device)           # a new host thread starts on device 0: bind it to this rank's GPU
         si = next((i for i, ww in enumerate(workers) if ww is w), 0)
         import threading
@@ -562,14 +594,14 @@ def main():
                 pass
         with torch.cuda.stream(w["stream"]):
             for k in ks:
-                one_pass(w, k)
+                one_pass(w, k, second)
 
-    def run_passes(ks):
+    def run_passes(ks, second=False):
         import threading
         if S == 1:
-            run_worker(workers[0], ks)
+            run_worker(workers[0], ks, second)
         else:
-            ths = [threading.Thread(target=run_worker, args=(w, ks)) for w in workers]
+            ths = [threading.Thread(target=run_worker, args=(w, ks, second)) for w in workers]
             for t in ths:
                 t.start()
             for t in ths:
@@ -595,6 +627,9 @@ def main():
     for wi in range(max(args.warmup, 1)):
         run_passes([-1 - wi])
         torch.cuda.synchronize()
+        if sec:
+            run_passes([-1 - wi], True)
+            torch.cuda.synchronize()
     if not os.environ.get("VB_NO_GRAPH") and not all(w["eng"].graphs() for w in workers):
         # the library captures the sampler loop the SECOND time it sees a call's buffers (the first call warms every kernel's
         # one-time attributes outside a capture): with --warmup 1 that capture + instantiation (tens of ms) would land in the
@@ -602,6 +637,7 @@ def main():
         run_passes([-50])
         torch.cuda.synchronize()
     assert all(torch.isfinite(w["wav"]).all() for w in workers)
+    assert not sec or all(torch.isfinite(w["sec"]["wav"]).all() for w in workers)
 
     # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every 7th launch of each class bracketed by
     # HIP events on the launch stream.  This is the kernel-quality figure (roofline.frac): in the timed region below two
@@ -611,7 +647,21 @@ def main():
                          # counts of the other classes (200, 129, 18).  Bracketing EVERY launch is not an option: back-to-back event pairs
                          # double the reading of the long conv kernels (60.8 ms against rocprofv3's 30), while a sampled launch between
                          # un-bracketed neighbours agrees with rocprofv3 to 2 %.
-    table, dominant = [], 0
+    table, table_sec, dominant = [], [], 0
+
+    def class_rows(per, cls_meta, passes):
+        rows = []
+        for cls, (ms, fl, by, n, nt) in per.items():
+            if nt == 0:
+                continue
+            name, bound, peak = cls_meta[cls]
+            tf, tbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e12
+            rows.append({"class": name, "bound": bound, "launches_per_pass": n / passes, "timed_launches": nt, "avg_launch_us": 1e3 * ms / nt,
+                         "ms_per_pass": ms * n / nt / passes, "algorithmic_gflop_per_launch": fl / nt / 1e9, "algorithmic_mb_per_launch": by / nt / 1e6,
+                         "tflops": tf, "frac_of_mfma_peak": tf / peak, "mfma_peak_tflops": peak, "algorithmic_tb_per_s": tbs,
+                         "frac_of_hbm_peak": tbs / HBM_PEAK_TBS})
+        return rows
+
     if not args.no_isolated:
         w = workers[0] if S == 1 else make_worker(B, rank * B, share=workers[0]["eng"])
         run_worker(w, [-100])
@@ -620,20 +670,19 @@ def main():
         PROF_PASSES = 3          # sampled launches per class: 3 x launches / 7 (the ResBlock-pair class makes 18 launches per pass)
         run_worker(w, [-101 - i for i in range(PROF_PASSES)])
         torch.cuda.synchronize()
-        per = {}
-        for cls in CLASSES:
-            ms, fl, by, n, nt = read_prof(cls)
-            per[cls] = (ms, fl, by, n, nt)
-            if nt == 0:
-                continue
-            name, bound, peak = CLASSES[cls]
-            tf, tbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e12
-            table.append({"class": name, "bound": bound, "launches_per_pass": n / PROF_PASSES, "timed_launches": nt, "avg_launch_us": 1e3 * ms / nt,
-                          "ms_per_pass": ms * n / nt / PROF_PASSES, "algorithmic_gflop_per_launch": fl / nt / 1e9, "algorithmic_mb_per_launch": by / nt / 1e6,
-                          "tflops": tf, "frac_of_mfma_peak": tf / peak, "mfma_peak_tflops": peak, "algorithmic_tb_per_s": tbs,
-                          "frac_of_hbm_peak": tbs / HBM_PEAK_TBS})
+        per = {cls: read_prof(cls) for cls in CLS}
+        table = class_rows(per, CLS, PROF_PASSES)
         L.check(lib.vb_prof_enable(0), "prof")
         dominant = max(per, key=lambda c: per[c][0] * (per[c][3] / per[c][4]) if per[c][4] else 0.0)
+        if sec:
+            # the convolution classes once more with the bf16x3 nets (classes 2 and 3 only: the DiT classes do not change)
+            run_worker(w, [-110], True)
+            torch.cuda.synchronize()
+            L.check(lib.vb_prof_enable(0xC | (EVERY << 8)), "prof")
+            run_worker(w, [-111 - i for i in range(PROF_PASSES)], True)
+            torch.cuda.synchronize()
+            table_sec = class_rows({cls: read_prof(cls) for cls in (2, 3)}, classes_for(sec), PROF_PASSES)
+            L.check(lib.vb_prof_enable(0), "prof")
         if S > 1:
             del w
             torch.cuda.empty_cache()
@@ -642,7 +691,7 @@ def main():
     # the dominant class bracketed inside the timed region (slower: the event records and ~6000 host launches per pass).
     if args.profile_timed:
         L.check(lib.vb_prof_enable((1 << dominant) | (8 << 8)), "prof")
-    log(f"warmup done; dominant class = {CLASSES[dominant][0]}; timing {args.steps} step(s)")
+    log(f"warmup done; dominant class = {CLS[dominant][0]}; timing {args.steps} step(s)")
 
     barrier()
     with Telemetry() as tele:
@@ -662,69 +711,100 @@ def main():
     log(f"timed region: {elapsed:.3f}s")
     ms, fl, by, n, nt = read_prof(dominant) if args.profile_timed else (0.0, 0.0, 0.0, 0, 0)
     L.check(lib.vb_prof_enable(0), "prof")
+    elapsed_sec, per_rank_ms_sec = None, None
+    if sec:
+        # the same K passes with the bf16x3 VAE / vocoder, timed the same way (barrier + synchronize on both sides, max over ranks)
+        barrier()
+        t0 = time.perf_counter()
+        run_passes(list(range(args.steps)), True)
+        barrier()
+        elapsed_sec = time.perf_counter() - t0
+        per_rank_ms_sec = [1e3 * elapsed_sec / args.steps]
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed_sec], device=device, dtype=torch.float64)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank_ms_sec = [1e3 * float(v.item()) / args.steps for v in allt]
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_sec = float(t.item())
+        log(f"second timed region ({sec} VAE / vocoder): {elapsed_sec:.3f}s")
 
-    parity = None
-    if rank == 0 and not args.no_parity_check and args.flow_steps == 50 and args.scale == 3.0 and args.precision == "bf16" and args.steps >= 1:
-        # one oracle fixture per workload shape: 20 s clips with 4 / 8 experts (clip 0 does not depend on the batch it rides in), and
-        # the 120 s long-form clip whose window rows / noise keys depend on the batch (4)
+    def verify(slots, label, with_flips):
+        """everything a timed region produced that an oracle fixture covers: clip 0 of pass 0 against the workload's digest; on the default
+        command also global clips 0, 4 (first clip of each sub-batch / stream) and 7 (last row of the batch: the partial-tile edge of every
+        token-row launch) on the first timed pass (graph replay #1 of this seed) and on pass 1 (a replay with another seed), every kept output
+        finite, and - when the last pass is neither - the last pass bitwise against an EAGER run of the same seed; with_flips: the
+        teacher-forced routing-flip count per block.  `slots` = per worker, the result slots of the precision being verified."""
         fixture = None
         if not long and abs(args.seconds - 20.0) < 1e-9 and args.experts in (4, 8):
             fixture = "bench_clip0.npz" if args.experts == 4 else "bench_clip0_e8.npz"
         elif long and abs(args.seconds - 120.0) < 1e-9 and args.experts == 4 and args.batch == 4 and S == 1:
             fixture = "bench_clip0_long.npz"
-        if fixture:
-            parity = parity_check(workers[0]["z0"], workers[0]["mel0"], fixture)
-            log(f"parity vs oracle digest: {parity}")
-        # ---- everything the timed region produced that an oracle fixture covers (default command only): the first clip of EVERY
-        # sub-batch / stream (global clips 0 and 4), on the first timed pass (graph replay #1 of this seed), on pass 1 (a replay with
-        # another seed) and - when the last pass is neither - the last pass bitwise against an EAGER run of the same seed; plus the
-        # teacher-forced routing-flip count per block.  A failure anywhere fails the run (exit code 3).
+        if not fixture:
+            return None
+        par = parity_check(slots[0]["z0"], slots[0]["mel0"], fixture)
+        log(f"[{label}] parity vs oracle digest: {par}")
         g = checks_fixture() if fixture == "bench_clip0.npz" else None
-        if parity is not None and g is not None:
-            rows, finite = [], True
-            for w in workers:
-                for ps, (z, mel) in sorted(w["kept"].items()):
-                    finite = finite and bool(torch.isfinite(z).all()) and bool(torch.isfinite(mel).all())
-                    if ps not in (0, 1):
-                        continue
-                    for c in (0, 4):
-                        r = c - w["clip_base"]
-                        if 0 <= r < w["nclips"]:
-                            rows.append(compare_with_oracle(z[r:r + 1], mel[r:r + 1], g, c, ps))
-            last = args.steps - 1
-            replay_eq = None
-            if last not in (0, 1) and all(w["eng"].graphs() for w in workers):
-                replay_eq = True
-                for w in workers:
-                    with torch.cuda.stream(w["stream"]):
-                        cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_lat, persistent=True)
-                        z_e, _ = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + last, clip_base=w["clip_base"], return_traj=True)
-                    torch.cuda.synchronize()
-                    replay_eq = replay_eq and bool(torch.equal(z_e, w["kept"][last][0]))
+        if par is None or g is None:
+            return par
+        clips = [int(c) for c in g["clips"]] if "clips" in g else [0, 4]
+        rows, finite = [], True
+        for w, n in zip(workers, slots):
+            for ps, (z, mel) in sorted(n["kept"].items()):
+                finite = finite and bool(torch.isfinite(z).all()) and bool(torch.isfinite(mel).all())
+                if ps not in (0, 1):
+                    continue
+                for c in clips:
+                    r = c - w["clip_base"]
+                    if 0 <= r < w["nclips"]:
+                        rows.append(compare_with_oracle(z[r:r + 1], mel[r:r + 1], g, c, ps))
+        last = args.steps - 1
+        replay_eq = None
+        if last not in (0, 1) and all(w["eng"].graphs() for w in workers):
+            replay_eq = True
+            for w, n in zip(workers, slots):
+                with torch.cuda.stream(w["stream"]):
+                    cond = w["eng"].precompute_cond(w["t5"], w["midi"], w["beats"], T_lat, persistent=True)
+                    z_e, _ = w["eng"].sample_cfg(w["x0"], cond, idx, dts, args.scale, seed=SEED + last, clip_base=w["clip_base"], return_traj=True)
+                torch.cuda.synchronize()
+                replay_eq = replay_eq and bool(torch.equal(z_e, n["kept"][last][0]))
+        par["verified"] = {"clips_x_passes": rows, "all_outputs_finite": finite,
+                           "last_pass": ("pass %d is covered by the oracle fixture" % last) if last in (0, 1) else
+                                        {"pass": last, "graph_replay_equals_eager_bitwise": replay_eq},
+                           "against": "tests/golden/bench_c2_checks.npz (oracle/gen_bench_digest.py --checks, --checks-add 7)"}
+        flips_ok = True
+        if with_flips:
             with torch.cuda.stream(workers[0]["stream"]):
                 flips = routing_flips(workers[0], g)
             torch.cuda.synchronize()
             flips_ok = flips["rate"] <= 2e-4
-            parity["verified"] = {"clips_x_passes": rows, "all_outputs_finite": finite,
-                                  "last_pass": ("pass %d is covered by the oracle fixture" % last) if last in (0, 1) else
-                                               {"pass": last, "graph_replay_equals_eager_bitwise": replay_eq},
-                                  "against": "tests/golden/bench_c2_checks.npz (oracle/gen_bench_digest.py --checks)"}
-            parity["routing_flips"] = flips
-            parity["ok"] = bool(parity["ok"] and finite and all(r["ok"] for r in rows) and replay_eq is not False and flips_ok)
-            log(f"verified {len(rows)} clip x pass outputs against the oracle: " + ", ".join(f"c{r['clip']}p{r['pass']} {r['latent_rel_l2']:.1e}" for r in rows) +
-                f"; finite {finite}; last-pass replay == eager: {replay_eq}; routing flips per block {flips['per_block']} of {flips['decisions_per_block']}")
+            par["routing_flips"] = flips
+        par["ok"] = bool(par["ok"] and finite and all(r["ok"] for r in rows) and replay_eq is not False and flips_ok)
+        log(f"[{label}] verified {len(rows)} clip x pass outputs against the oracle: " + ", ".join(f"c{r['clip']}p{r['pass']} {r['latent_rel_l2']:.1e}" for r in rows) +
+            f"; finite {finite}; last-pass replay == eager: {replay_eq}" +
+            (f"; routing flips per block {par['routing_flips']['per_block']} of {par['routing_flips']['decisions_per_block']}" if with_flips else ""))
+        return par
+
+    parity, parity_sec = None, None
+    if rank == 0 and not args.no_parity_check and args.flow_steps == 50 and args.scale == 3.0 and args.precision == "bf16" and args.steps >= 1:
+        # one oracle fixture per workload shape: 20 s clips with 4 / 8 experts (clip 0 does not depend on the batch it rides in), and
+        # the 120 s long-form clip whose window rows / noise keys depend on the batch (4).  A failure anywhere fails the run (exit code 3).
+        parity = verify(workers, f"{prim} VAE / vocoder", True)
+        if sec:
+            parity_sec = verify([w["sec"] for w in workers], f"{sec} VAE / vocoder", False)
 
     if rank == 0:
-        name, bound, peak = CLASSES[dominant]
+        name, bound, peak = CLS[dominant]
         conc = (fl / (ms * 1e-3) / 1e12) if (ms > 0 and nt > 0) else 0.0      # flops and time of the timed launches
         iso = next((r for r in table if r["class"] == name), None)
         achieved = iso["tflops"] if iso else conc
         # the committed PMC passes were taken on the default command (c2, 8 clips): for any other workload the per-launch figure does not apply
         pmc_applies = args.workload == "c2" and B == 8 and args.experts == 4 and abs(clip_seconds - 20.0) < 1e-9
-        traffic, traffic_file, traffic_how = None, None, None
+        traffic, traffic_file, traffic_how, traffic_table = None, None, None, None
         if pmc_applies and world == 1 and not args.no_pmc:
             log("PMC traffic passes (rocprofv3 child runs)")
-            traffic, traffic_how = pmc_traffic_live(dominant, args.pmc_timeout)
+            traffic, traffic_how, traffic_table = pmc_traffic_live(dominant, args.pmc_timeout, prim)
             log(f"traffic: {traffic} ({traffic_how})")
         if traffic is None and pmc_applies:
             live_why = traffic_how
@@ -752,14 +832,16 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("bf16 DiT (fp32 accumulate)" if args.precision == "bf16" else "bf16x3 split DiT") +
-                     (" + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32" if args.vocoder_precision == "split" else
+                     (" + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32" if prim == "split" else
                       " + fp32 VAE/vocoder (v_mfma_f32_32x32x2_f32, exact fp32 products)"),
             "data": "synthetic (seeded PRNG clips, random-init checkpoints of the configured architecture)",
             "config": {"workload": wl + f", {args.flow_steps} Euler steps x 2 NFE (CFG scale {args.scale}), Band-MoE E={args.experts}, "
                                         "VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml; VAE / vocoder arithmetic: " +
                                         ("split-bf16 (bf16x3 products, fp32 I/O and accumulation, <= 3e-5 of exact fp32; `--vocoder-precision fp32` "
-                                         "runs the literal fp32 kernels)" if args.vocoder_precision == "split" else "exact fp32 (f32 MFMA)"),
-                       "vocoder_precision": args.vocoder_precision,
+                                         "runs the literal fp32 kernels)" if prim == "split" else
+                                         "exact fp32 (f32 MFMA, configs[1] as written)" + ("; the same K passes with the bf16x3 VAE / vocoder are timed in a "
+                                                                                            "second region and reported under `split`" if sec else "")),
+                       "vocoder_precision": prim,
                        "baseline_config": {"c2": "configs[1]", "c3": "configs[2]", "c5": "configs[4]"}[args.workload],
                        "clips_per_gpu": B, "clip_seconds": clip_seconds, "flow_steps": args.flow_steps, "precision": args.precision, "experts": args.experts,
                        "sampler_loop": ("hipGraph replay (%d graph(s) on rank 0)" % sum(w["eng"].graphs() for w in workers))
@@ -772,7 +854,7 @@ def main():
                                  "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 7th "
                                  "launch bracketed by HIP events on the launch stream)") if iso else "timed-region launches (no isolated pass)",
                          "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_per_kernel": traffic_table,
                          "traffic_source": traffic_how if pmc_applies else
                                            "none for this workload: the PMC passes cover the default c2 command only",
                          "algorithmic_bytes_per_launch": (iso["algorithmic_mb_per_launch"] * 1e6) if iso else None,
@@ -785,11 +867,18 @@ def main():
                                           "for eager launches + in-region events)"),
                          "classes": table},
         }
+        if sec:
+            out["split"] = {
+                "what": "the same workload and the same K passes with the VAE / vocoder on split-bf16 (bf16x3: every product as hi*hi + lo*hi + hi*lo on "
+                        "the bf16 MFMA pipe, fp32 I/O and accumulation, <= 3e-5 of exact fp32) - narrower than the fp32 arithmetic configs[1] names, "
+                        "so it is reported beside `value`, not as it",
+                "value": total_mel_s / elapsed_sec, "unit": "mel-s/s", "ms_per_step": 1e3 * elapsed_sec / args.steps, "steps": args.steps,
+                "per_rank_ms": per_rank_ms_sec, "vocoder_precision": sec, "parity_check": parity_sec, "classes": table_sec}
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out))
-        if parity is not None and parity.get("ok") is False:
+        if (parity is not None and parity.get("ok") is False) or (parity_sec is not None and parity_sec.get("ok") is False):
             log("PARITY CHECK FAILED")
     if args.save_out:
         import numpy as np
@@ -802,7 +891,7 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and parity is not None and parity.get("ok") is False:
+    if rank == 0 and ((parity is not None and parity.get("ok") is False) or (parity_sec is not None and parity_sec.get("ok") is False)):
         sys.exit(3)
 
 

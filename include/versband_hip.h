@@ -202,7 +202,8 @@ typedef struct {
     int Ci, Co, ksize, dil, pad, upsample2, in_act, out_act, out_transposed, tr_stride, tr_pad, tr_k, gn_groups;
     float in_slope, out_slope, alpha, beta, acc_scale;
     const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
-    const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution */
+    const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution (w_x3 == NULL: exact-fp32 pair, w and w2_x3 are the fp32
+                                              * packed [k][Ci][Co] weights of the two convolutions; channels 32 / 64 / 128) */
     int in_stride, in_phase;                 /* VB_OP_CONV: the convolution reads x[i*in_stride + in_phase] (0/1 = plain) */
     int x_planes;                            /* VB_OP_CONV: x is a VB_OP_XT_PLANES buffer (upsample2 then describes how it was made) */
 } vb_net_op;
@@ -295,6 +296,11 @@ int vb_attention(const void* q, const void* k, const void* vt, const void* ky, c
 int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil, int pad,
                   int tr_stride, int tr_pad, int tr_k, int T_out, int in_act, float in_slope, const float* res, float* out,
                   const void* w_x3, int ci_pad, void* stream);
+/* HiFi-GAN ResBlock1 pair in exact fp32, one launch (vocoder/hifigan/modules/hifigan.py:27-64; respair_f32.hip):
+ * out = beta*out + alpha*(x + b2 + conv2_{k,1}(lrelu(b1 + conv1_{k,dil}(lrelu(x))))), x / out [B][C][T] (distinct buffers), weights fp32
+ * packed [k][C ci][C co]; C = 32 / 64 / 128, odd k <= 17, (k-1)*dil <= 60, T % 4 == 0.  Equals two vb_conv1d_f32 launches bit for bit. */
+int vb_respair_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C, int T, int k, int dil,
+                   float slope, float alpha, float beta, float* out, void* stream);
 /* counter-based Gumbel draws: out[rows][w], rows = n_branch*B*T */
 int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
                    void* stream);

@@ -14,6 +14,7 @@ compare the HIP path's bf16 production output with it at north_star's tolerances
                                                     # (seed 1234 and 1235: pass 1 is the first hipGraph REPLAY of the timed region), plus the
                                                     # oracle's states x_k and routing indices of clip 0 / pass 0 at six steps for the
                                                     # teacher-forced routing-flip count -> tests/golden/bench_c2_checks.npz, ~10 min of CPU
+    python oracle/gen_bench_digest.py --checks-add 7   # round 4: add global clip 7 (last row of the second sub-batch) x passes 0 and 1 to it
 """
 import os
 import sys
@@ -79,16 +80,25 @@ def main_long():
 TF_STEPS = (0, 10, 20, 30, 40, 49)     # Euler steps whose oracle state + routing indices are kept for the teacher-forced flip count
 
 
-def main_checks():
+def main_checks(add_clips=None):
     """clip c of pass p of `python bench.py` = global clip index c, sampler seed SEED + p (bench.py:one_pass), router noise keyed by
-    (seed, global clip, evaluation index = Euler step, branch, block, gate)."""
+    (seed, global clip, evaluation index = Euler step, branch, block, gate).
+    add_clips (--checks-add 7): keep the committed entries and add these clips (round 4: global clip 7 = the last row of the second
+    sub-batch, i.e. the partial-tile edge of every token-row launch)."""
     torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     dcfg, vcfg = synth.DiTConfig(num_experts=E), synth.VAEConfig()
     sd = synth.make_state_dict(synth.dit_shapes(dcfg), SEED)
     sdv = synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1)
-    out = {"meta": np.array([SEED, T, L, E, STEPS], dtype=np.int64), "scale": np.float32(SCALE), "clips": np.array([0, 4], dtype=np.int64),
-           "passes": np.array([0, 1], dtype=np.int64), "tf_steps": np.array(TF_STEPS, dtype=np.int64)}
-    for clip in (0, 4):
+    path = os.path.join(ROOT, "tests", "golden", "bench_c2_checks.npz")
+    if add_clips:
+        out = dict(np.load(path))
+        out["clips"] = np.array(sorted(set(int(c) for c in out["clips"]) | set(add_clips)), dtype=np.int64)
+        todo = tuple(add_clips)
+    else:
+        out = {"meta": np.array([SEED, T, L, E, STEPS], dtype=np.int64), "scale": np.float32(SCALE), "clips": np.array([0, 4], dtype=np.int64),
+               "passes": np.array([0, 1], dtype=np.int64), "tf_steps": np.array(TF_STEPS, dtype=np.int64)}
+        todo = (0, 4)
+    for clip in todo:
         inp = clip_batch(1, T, L, clip0=clip, seed=SEED)
         cc = ref_cpu.dit_precompute(sd, inp["t5_cond"], inp["midi"], inp["beats"], T)
         cu = ref_cpu.dit_precompute(sd, inp["t5_uncond"], inp["midi"], inp["beats"], T)
@@ -122,7 +132,6 @@ def main_checks():
             out[f"z_c{clip}_p{ps}"] = x.numpy()
             out.update(digest(mel, f"mel_c{clip}_p{ps}_"))
             print(f"clip {clip} pass {ps} done", flush=True)
-    path = os.path.join(ROOT, "tests", "golden", "bench_c2_checks.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
 
@@ -130,6 +139,8 @@ def main_checks():
 def main():
     if "--long" in sys.argv:
         return main_long()
+    if "--checks-add" in sys.argv:
+        return main_checks([int(v) for v in sys.argv[sys.argv.index("--checks-add") + 1].split(",")])
     if "--checks" in sys.argv:
         return main_checks()
     E = int(sys.argv[sys.argv.index("--experts") + 1]) if "--experts" in sys.argv else 4

@@ -346,3 +346,122 @@ def test_staged_conv_epilogues_are_bit_identical(lib, monkeypatch):
         lib.vb_tune_reload()
         sync()
         assert torch.isfinite(a).all() and torch.equal(a, b), f"T={T}: staged vs direct epilogue differ by {float((a - b).abs().max()):.3e}"
+
+
+# ---------------------------------------------------------------- exact-fp32 DMA-fed conv / fused pair (round 4) ------
+G_CASES = [  # B, Ci, T, Co, k, dil, in_act, res  - every case takes conv1d_f32g_kernel (Ci % 16 == 0, Co % 4 == 0, T % 4 == 0)
+    (2, 32, 1000, 32, 11, 5, 1, True),      # 32 x 256 tiles, ragged last tile, both clip ends inside a window
+    (1, 64, 520, 64, 7, 3, 1, True),        # 64 x 128 tiles
+    (2, 128, 388, 128, 3, 1, 1, True),      # 128 x 128 tiles, one channel tile
+    (1, 256, 260, 256, 11, 1, 1, False),    # two channel tiles
+    (2, 1536, 100, 768, 3, 1, 0, False),    # 96 chunks: the window / weight rings wrap many times
+    (1, 384, 1504, 80, 5, 1, 0, False),     # Co < channel tile
+    (1, 48, 132, 100, 1, 1, 0, True),       # k = 1: a new window every ring step; Co not a multiple of 32
+    (1, 16, 64, 36, 2, 1, 0, False),        # one chunk, two taps
+    (3, 128, 752, 1536, 3, 1, 0, False),    # 96-sample tiles win the tile choice at this shape
+]
+
+
+def _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, act, tr=(1, 0, 0), T_out=None):
+    T_out = T if T_out is None else T_out
+    out = torch.full((B, Co, T_out), float("nan"), device="cuda")
+    L.check(lib.vb_conv1d_f32(L.ptr(x), L.ptr(wpk), L.ptr(b), B, Ci, T, Co, k, dil, pad, tr[0], tr[1], tr[2], T_out, act, 0.1,
+                              L.ptr(r) if r is not None else None, L.ptr(out), None, 0, L.stream_ptr()), "conv")
+    sync()
+    return out
+
+
+@pytest.mark.parametrize("B,Ci,T,Co,k,dil,act,res", G_CASES)
+def test_fp32_dma_conv_is_bit_identical_to_register_staged(lib, monkeypatch, B, Ci, T, Co, k, dil, act, res):
+    """conv1d_f32g_kernel (window and weight tiles by global_load_lds, LeakyReLU on the fragment, staged epilogue) keeps the chunk ->
+    tap -> channel-pair order of conv1d_f32_kernel (VB_CONV_F32_OLD=1): same bits; and both are fp32-roundoff close to float64."""
+    x, w, b = dev(rnd((B, Ci, T), "gx")), rnd((Co, Ci, k), "gw", 1.0 / (Ci * k) ** 0.5), dev(rnd((Co,), "gb"))
+    r = dev(rnd((B, Co, T), "gr")) if res else None
+    pad = (k - 1) * dil // 2
+    wpk = dev(pack.pack_conv(w))
+    T_out = T + 2 * pad - dil * (k - 1)
+    new = _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, act, T_out=T_out) if T_out == T else None
+    if new is None:      # even k: the output is one sample shorter; the residual must match it
+        r = r[:, :, :T_out].contiguous() if r is not None else None
+        new = _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, act, T_out=T_out)
+    monkeypatch.setenv("VB_CONV_F32_OLD", "1")
+    lib.vb_tune_reload()
+    old = _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, act, T_out=T_out)
+    monkeypatch.delenv("VB_CONV_F32_OLD")
+    lib.vb_tune_reload()
+    assert torch.isfinite(new).all() and torch.equal(new, old), f"DMA-fed vs register-staged differ by {float((new - old).abs().max()):.3e}"
+    xin = F.leaky_relu(x.double().cpu(), 0.1) if act else x.double().cpu()
+    ref = F.conv1d(xin, w.double(), b.double().cpu(), dilation=dil, padding=pad)
+    if res:
+        ref = ref + r.double().cpu()
+    assert rel_l2(new, ref) < 2e-6, describe("conv1d fp32 dma", new, ref)
+
+
+@pytest.mark.parametrize("B,Ci,T,Co,k,u", [(2, 512, 24, 256, 16, 8), (1, 256, 32, 128, 15, 5), (2, 64, 52, 32, 4, 2), (1, 128, 20, 64, 8, 4)])
+def test_fp32_dma_conv_transpose_is_bit_identical(lib, monkeypatch, B, Ci, T, Co, k, u):
+    x, w, b = dev(rnd((B, Ci, T), "hx")), rnd((Ci, Co, k), "hw", (u / (Ci * k)) ** 0.5), dev(rnd((Co,), "hb"))
+    p = (k - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x.double().cpu(), 0.1), w.double(), b.double().cpu(), stride=u, padding=p)
+    T_out = ref.shape[-1]
+    wpk = dev(pack.pack_conv_transpose(w, u))
+    new = _conv_f32(lib, x, wpk, b, None, B, Ci, T, Co, 0, 1, 0, 1, tr=(u, p, k), T_out=T_out)
+    monkeypatch.setenv("VB_CONV_F32_OLD", "1")
+    lib.vb_tune_reload()
+    old = _conv_f32(lib, x, wpk, b, None, B, Ci, T, Co, 0, 1, 0, 1, tr=(u, p, k), T_out=T_out)
+    monkeypatch.delenv("VB_CONV_F32_OLD")
+    lib.vb_tune_reload()
+    assert torch.isfinite(new).all() and torch.equal(new, old)
+    assert rel_l2(new, ref) < 2e-6, describe("conv_transpose1d fp32 dma", new, ref)
+
+
+@pytest.mark.parametrize("B,C,T,k,dil,alpha,beta", [(2, 32, 1000, 3, 1, 1.0, 0.0), (1, 32, 472, 11, 5, 1.0 / 3, 1.0), (2, 64, 600, 7, 3, 1.0, 0.0),
+                                                   (1, 64, 244, 11, 5, 1.0 / 3, 1.0), (1, 64, 128, 3, 5, 1.0 / 3, 0.0),
+                                                   (1, 128, 360, 7, 1, 1.0, 0.0), (2, 128, 120, 11, 3, 1.0 / 3, 1.0)])
+def test_fp32_respair_equals_two_fp32_convolutions(lib, B, C, T, k, dil, alpha, beta):
+    """respair_f32_kernel (vocoder/hifigan/modules/hifigan.py:27-64 ResBlock1 pair, intermediate kept in LDS) against the two launches
+    of the fp32 convolution kernel it replaces: same accumulation order, same epilogue arithmetic - equal bit for bit (torch.equal
+    treats the two zeros alike), incl. the accumulate-into-the-MRF-sum form (alpha = 1/3, beta = 1) and both clip ends."""
+    x = dev(rnd((B, C, T), "px"))
+    w1, w2 = rnd((C, C, k), "pw1", 1.0 / (C * k) ** 0.5), rnd((C, C, k), "pw2", 1.0 / (C * k) ** 0.5)
+    b1, b2 = dev(rnd((C,), "pb1")), dev(rnd((C,), "pb2"))
+    acc0 = dev(rnd((B, C, T), "pacc"))
+    p1, p2 = dev(pack.pack_conv(w1)), dev(pack.pack_conv(w2))
+    fused = acc0.clone()
+    L.check(lib.vb_respair_f32(L.ptr(x), L.ptr(p1), L.ptr(b1), L.ptr(p2), L.ptr(b2), B, C, T, k, dil, 0.1, alpha, beta, L.ptr(fused),
+                               L.stream_ptr()), "respair_f32")
+    sync()
+    t1 = _conv_f32(lib, x, p1, b1, None, B, C, T, C, k, dil, (k - 1) * dil // 2, 1)
+    t2 = _conv_f32(lib, t1, p2, b2, x, B, C, T, C, k, 1, (k - 1) // 2, 1)
+    ref64 = F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w1.double(), b1.double().cpu(), dilation=dil,
+                                           padding=(k - 1) * dil // 2), 0.1), w2.double(), b2.double().cpu(), padding=(k - 1) // 2) + x.double().cpu()
+    ref64 = alpha * ref64 + beta * acc0.double().cpu()
+    assert torch.isfinite(fused).all()
+    assert rel_l2(fused, ref64) < 2e-6, describe("respair fp32", fused, ref64)
+    if alpha == 1.0 and beta == 0.0:
+        assert torch.equal(fused, t2), f"fused pair vs two launches differ by {float((fused - t2).abs().max()):.3e}"
+
+
+def test_fp32_vocoder_fused_pairs_equal_unfused_launches(lib, monkeypatch):
+    """The whole generator in exact fp32 (BASELINE configs[1]: "fp32 vocoder"): ResBlock1 pairs fused at 32 / 64 channels
+    (respair_f32_kernel, incl. the accumulate-into-the-MRF-sum pairs with alpha = 1/3, beta = 1) against one launch per convolution
+    (VB_FP32_PAIRS=""), and the DMA-fed kernel against the register-staged one (VB_CONV_F32_OLD=1): the waveform is the same bit for bit."""
+    from versband_amd import synth
+    from versband_amd.engine import Context, build_hifigan
+    hcfg = synth.HifiGanConfig()
+    sdh = synth.make_state_dict(synth.hifigan_shapes(hcfg), 78)
+    ctx = Context("cuda:0")
+    mel = torch.from_numpy(prng.uniform(prng.key_seed(9, "melf"), 2 * 80 * 44, -5.0, 1.0).reshape(2, 80, 44)).cuda()
+    fused = build_hifigan(ctx, sdh, hcfg.as_hparams(), precision="fp32").run(mel).clone()
+    monkeypatch.setenv("VB_FP32_PAIRS", "")
+    unfused_net = build_hifigan(ctx, sdh, hcfg.as_hparams(), precision="fp32")
+    monkeypatch.delenv("VB_FP32_PAIRS")
+    unfused = unfused_net.run(mel).clone()
+    monkeypatch.setenv("VB_CONV_F32_OLD", "1")
+    lib.vb_tune_reload()
+    old = unfused_net.run(mel).clone()
+    monkeypatch.delenv("VB_CONV_F32_OLD")
+    lib.vb_tune_reload()
+    sync()
+    assert torch.isfinite(fused).all()
+    assert torch.equal(unfused, old), f"DMA-fed vs register-staged vocoder differ by {float((unfused - old).abs().max()):.3e}"
+    assert torch.equal(fused, unfused), f"fused pairs vs unfused differ by {float((fused - unfused).abs().max()):.3e}"

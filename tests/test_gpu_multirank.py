@@ -52,4 +52,8 @@ def test_c4_rank_shape_under_a_process_group():
     assert len(out["ranks"]["per_rank_ms"]) == 2 and all(v > 0 for v in out["ranks"]["per_rank_ms"])
     assert out["ranks"]["weight_broadcast_gbps"] > 0 and out["ranks"]["collectives_in_timed_region"] == 0
     assert "hipGraph replay" in out["config"]["sampler_loop"]
-    assert out["parity_check"]["ok"] is True and len(out["parity_check"]["verified"]["clips_x_passes"]) == 4
+    # rank 0 holds global clips 0..7: the fixture's clips 0, 4 (first clip of each sub-batch) and 7 (last row) x passes 0 and 1
+    assert out["parity_check"]["ok"] is True and len(out["parity_check"]["verified"]["clips_x_passes"]) == 6
+    # the default command times both VAE / vocoder precisions: `value` = fp32 (configs[1] as written), `split` = bf16x3, each verified
+    assert out["config"]["vocoder_precision"] == "fp32" and out["split"]["vocoder_precision"] == "split"
+    assert out["split"]["parity_check"]["ok"] is True and out["split"]["value"] > 0 and len(out["split"]["per_rank_ms"]) == 2

@@ -155,21 +155,25 @@ def test_c5_longform_bf16_production_clip_vs_oracle_fixture(prod):
 
 def test_c2_second_stream_clip_and_replay_seed_vs_oracle_fixture(prod):
     """what bench.py verifies beyond clip 0 of pass 0 (tests/golden/bench_c2_checks.npz): global clip 4 - the first clip of the
-    second sub-batch / stream - with the sampler seed of pass 1 (SEED + 1), riding in a batch of 2 at clip_base 4."""
+    second sub-batch / stream - and global clip 7 - the LAST row of that sub-batch, the partial-tile edge of every token-row launch
+    (round 4) - with the sampler seeds of passes 0 and 1, riding in a batch of 4 at clip_base 4 as they do in the benchmark."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bench_c2_checks.npz"))
-    T, Lc, B = 752, 80, 2
+    assert [int(c) for c in g["clips"]] == [0, 4, 7]
+    T, Lc, B = 752, 80, 4
     inp = clip_batch(B, T, Lc, clip0=4, seed=SEED)
     idx, dts = vm.euler_tables(51)
     eng = prod["eng"]
     cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
     for ps in (0, 1):
         z = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=SEED + ps, clip_base=4)
-        mel = prod["vae"].run(z[:1].contiguous())
-        torch.cuda.synchronize()
-        z_ref = torch.from_numpy(g[f"z_c4_p{ps}"]).double()
-        rel = float((z[:1].double().cpu() - z_ref).norm() / z_ref.norm())
-        m = mel.double().cpu().reshape(-1)
-        l1 = float((m[torch.from_numpy(g[f"mel_c4_p{ps}_idx"])] - torch.from_numpy(g[f"mel_c4_p{ps}_val"])).abs().mean())
-        print(f"clip 4, pass {ps}: latent rel-L2 {rel:.3e}, mel L1 {l1:.3e}")
-        assert rel <= LATENT_TOL and l1 < MEL_L1_TOL
+        for clip in (4, 7):
+            r = clip - 4
+            mel = prod["vae"].run(z[r:r + 1].contiguous())
+            torch.cuda.synchronize()
+            z_ref = torch.from_numpy(g[f"z_c{clip}_p{ps}"]).double()
+            rel = float((z[r:r + 1].double().cpu() - z_ref).norm() / z_ref.norm())
+            m = mel.double().cpu().reshape(-1)
+            l1 = float((m[torch.from_numpy(g[f"mel_c{clip}_p{ps}_idx"])] - torch.from_numpy(g[f"mel_c{clip}_p{ps}_val"])).abs().mean())
+            print(f"clip {clip}, pass {ps}: latent rel-L2 {rel:.3e}, mel L1 {l1:.3e}")
+            assert rel <= LATENT_TOL and l1 < MEL_L1_TOL

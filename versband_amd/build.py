@@ -19,11 +19,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libversband_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "respair_x3.hip", "t5.hip", "melnet.hip", "elementwise.hip", "rowlin.hip",
+SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "conv1d_f32g.hip", "respair_x3.hip", "respair_f32.hip", "t5.hip", "melnet.hip", "elementwise.hip", "rowlin.hip",
            "engine.hip"]
 EXPERIMENT_SOURCES = ["score_router.hip"]
 EXPERIMENTS = bool(os.environ.get("VB_BUILD_EXPERIMENTS"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DVB_EXPERIMENTS"] if EXPERIMENTS else [])
+# the exact-fp32 kernels keep their MFMA accumulators in VGPRs (hipcc otherwise copies them to AGPRs and back around every ring step of
+# the asm-pipelined loops: 32 v_accvgpr moves per 32 MFMAs)
+EXTRA_FLAGS = {"conv1d_f32g.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "respair_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 MARKER = b"VB_SOURCE_DIGEST="
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "versband_hip.h")
 
@@ -47,6 +50,7 @@ def source_digest() -> str:
     h.update(b"../../include/versband_hip.h")
     h.update(open(PUBLIC_HEADER, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -102,10 +106,11 @@ def _build_locked(dg: str, force: bool, verbose: bool) -> str:
     def cc(src):
         out = os.path.join(OBJ, src.replace(".hip", ".o"))
         stamp = out + ".sha"
-        want = hashlib.sha256(hh + open(os.path.join(CSRC, src), "rb").read()).hexdigest()
+        extra = EXTRA_FLAGS.get(src, [])
+        want = hashlib.sha256(hh + " ".join(extra).encode() + open(os.path.join(CSRC, src), "rb").read()).hexdigest()
         if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == want:
             return out
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", out]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", out]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

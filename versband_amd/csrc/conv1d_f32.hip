@@ -22,155 +22,7 @@
 #define CK 16
 #define XHALO 64
 
-struct ConvDev {
-    const float* x; int64_t x_bstride; int Ci, T_in, x_bmod;
-    const float* w; int64_t w_bstride; const float* bias;
-    int Co, ntaps, dil, pad, upsample2;
-    int in_stride, in_phase;        // the convolution sees xd[i] = x[i * in_stride + in_phase] (strided down-convs as polyphase sums)
-    int in_act; float in_slope;
-    const float* gn_mean; const float* gn_rstd; const float* gn_gamma; const float* gn_beta; int gn_groups;
-    float* out; int64_t out_bstride; int T_out;
-    const float* res; int64_t res_bstride;
-    float alpha, beta, acc_scale;
-    int out_act; float out_slope;
-    int out_transposed; const float* add; int64_t add_bstride; int add_bmod;
-    int phases, tr_pad;      // phases == 1: ordinary convolution
-    const bf16_t* wp; int64_t wp_plane; int Ci_pad;   // split-bf16 weights [2 planes][phase][tap][Co][Ci_pad]
-    int64_t wp_bstride;
-    const bf16_t* xt; int64_t xt_plane; int xt_Tp;     // pre-activated transposed split planes of the input (XT mode)
-    int stage_epi;           // [b][co][t] output, stride 1, T_out % 4 == 0, 16-B aligned rows: the staged (16-B lane) epilogue
-};
-
-// One output element of the [b][co][t] epilogues.  The arithmetic is pinned (no implicit contraction, one explicit fma): the direct
-// and the staged epilogue - and every tile configuration - must round alike, bit for bit.
-__device__ __forceinline__ float conv_out_value(const ConvDev& p, float acc, float bias, float res, float old) {
-#pragma clang fp contract(off)
-    float val = acc * p.acc_scale;
-    val = val + bias;
-    val = val + res;
-    if (p.out_act == ACT_LRELU) val = val > 0.f ? val : val * p.out_slope;
-    else if (p.out_act == ACT_TANH) val = tanhf(val);
-    return fmaf(val, p.alpha, p.beta * old);
-}
-
-// Staged variant of the [b][co][t] epilogue.  The MFMA accumulator gives a lane ONE output position and 16 channels, so the direct
-// epilogue below moves every residual / accumulate-into load and every store as 4-byte lane accesses (two 128-B row pieces per
-// wave instruction) - on the narrow, long vocoder layers that epilogue was half of the kernel (tools/conv_bench.py noEpi column:
-// 743 -> 367 us at 128 channels, 1075 -> 267 us at 32).  Here each wave passes its 32 x 32 tiles through a PRIVATE 4.5-KB LDS
-// patch (no block barrier: only the wave's own writes precede its reads) and comes back with a lane owning 4 consecutive
-// positions of one channel: residual, accumulate-into and output move as 16-byte lane accesses, 8 full 128-B lines per wave
-// instruction.  Same arithmetic per element, same order: bit-identical to the direct form.
-#define CE_PITCH 36          // floats per staged channel row (32 + 4: keeps the 16-B reads aligned, spreads the rows over banks)
-template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue_staged(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
-                                                     float* stage) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
-    float* patch = stage + wave * (32 * CE_PITCH);
-    const int rr = lane >> 3, t4 = (lane & 7) * 4;           // read-back: channel row rr + 8k, positions t4 .. t4+3
-    float* ob = p.out + (int64_t)b * p.out_bstride;
-    const float* rb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int nb = n0 + (wn * TN + jn) * 32;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int cb = co0 + (wm * TM + i) * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) patch[(4 * g + 8 * (r >> 2) + (r & 3)) * CE_PITCH + l31] = acc[i][jn][r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): own writes landed (wave-private patch)
-            float4 v[4], rv[4], ov[4];
-            float bv[4];
-            bool ok[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int co = cb + rr + 8 * k, n = nb + t4;
-                ok[k] = co < p.Co && n < n_count;            // (n_count % 4 == 0 is a launch condition of this variant)
-                v[k] = *reinterpret_cast<const float4*>(patch + (rr + 8 * k) * CE_PITCH + t4);
-                const int64_t oi = (int64_t)(ok[k] ? co : 0) * p.T_out + (ok[k] ? n : 0);
-                rv[k] = (ok[k] && rb) ? *reinterpret_cast<const float4*>(rb + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ov[k] = (ok[k] && p.beta != 0.f) ? *reinterpret_cast<const float4*>(ob + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bv[k] = (ok[k] && p.bias) ? p.bias[co] : 0.f;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // the patch is read before the next tile overwrites it
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!ok[k]) continue;
-                const int co = cb + rr + 8 * k, n = nb + t4;
-                const float a4[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-                const float o4[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
-                float q[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = conv_out_value(p, a4[e], bv[k], r4[e], o4[e]);
-                *reinterpret_cast<float4*>(ob + (int64_t)co * p.T_out + n) = make_float4(q[0], q[1], q[2], q[3]);
-            }
-        }
-    }
-}
-
-template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
-                                              int out_stride, int out_off) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WN, wn = wave % WN;
-    // ---- epilogue: lane owns output position n, 4 consecutive co per accumulator quad.
-    // All loads of a 32x32 accumulator tile (residual, accumulate-into, transposed add) are issued BEFORE its first
-    // store: vmcnt retires loads and stores in order, so a load issued behind a store would wait for the store's
-    // round trip as well - interleaving them serialises 16 memory round trips per tile (measured: 3-4x slower layers).
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int n = n0 + (wn * TN + jn) * 32 + l31;
-        const bool nok = n < n_count;
-        const int t = n * out_stride + out_off;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int cobase = co0 + (wm * TM + i) * 32 + 4 * g;
-            if (p.out_transposed) {
-                // out[b][t][co..co+3]   (Co % 4 == 0 enforced at launch)
-                float4 ad[4];
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int cob = cobase + 8 * rg;
-                    ad[rg] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (nok && cob < p.Co && p.add) {
-                        const int ab = p.add_bmod > 0 ? (b % p.add_bmod) : b;
-                        ad[rg] = *reinterpret_cast<const float4*>(p.add + (int64_t)ab * p.add_bstride + (int64_t)t * p.Co + cob);
-                    }
-                }
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int cob = cobase + 8 * rg;
-                    if (!nok || cob >= p.Co) continue;
-                    float4 o;
-                    o.x = acc[i][jn][rg * 4 + 0] * p.acc_scale + (p.bias ? p.bias[cob + 0] : 0.f) + ad[rg].x;
-                    o.y = acc[i][jn][rg * 4 + 1] * p.acc_scale + (p.bias ? p.bias[cob + 1] : 0.f) + ad[rg].y;
-                    o.z = acc[i][jn][rg * 4 + 2] * p.acc_scale + (p.bias ? p.bias[cob + 2] : 0.f) + ad[rg].z;
-                    o.w = acc[i][jn][rg * 4 + 3] * p.acc_scale + (p.bias ? p.bias[cob + 3] : 0.f) + ad[rg].w;
-                    *reinterpret_cast<float4*>(p.out + (int64_t)b * p.out_bstride + (int64_t)t * p.Co + cob) = o;
-                }
-            } else {
-                float rv[16], ov[16], bv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cobase + 8 * (r >> 2) + (r & 3);
-                    const bool ok = nok && co < p.Co;
-                    const int64_t oi = (int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t;
-                    rv[r] = (ok && p.res) ? p.res[(int64_t)b * p.res_bstride + (int64_t)co * p.T_out + t] : 0.f;
-                    ov[r] = (ok && p.beta != 0.f) ? p.out[oi] : 0.f;
-                    bv[r] = (ok && p.bias) ? p.bias[co] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cobase + 8 * (r >> 2) + (r & 3);
-                    if (!nok || co >= p.Co) continue;
-                    p.out[(int64_t)b * p.out_bstride + (int64_t)co * p.T_out + t] = conv_out_value(p, acc[i][jn][r], bv[r], rv[r], ov[r]);
-                }
-            }
-        }
-    }
-}
+#include "conv1d_dev.h"
 
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(256) conv1d_f32_kernel(const ConvDev p) {
@@ -612,6 +464,13 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
         else if (a.Co > 32 && cfgv == 1) launch_cfg_x3<2, 2, 1, 4>(d, n_count, a.B, st);
         else if (a.Co > 32) launch_cfg_x3<2, 2, 1, 2>(d, n_count, a.B, st);
         else launch_cfg_x3<1, 4, 1, 2>(d, n_count, a.B, st);
+    } else if (!a.wp && a.w_bstride % 4 == 0 && !a.x_bmod && d.in_stride == 1 && (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && a.Ci % GK == 0 &&
+               a.Co % 4 == 0 && (d.ntaps - 1) * d.dil <= 60 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 &&
+               (a.upsample2 ? (a.Co > 64 && d.phases == 1)
+                            : (a.T_in % 4 == 0 && a.x_bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0)) &&
+               !vb_tune().conv_f32_old) {
+        // exact fp32, DMA-fed (conv1d_f32g_kernel); VB_CONV_F32_OLD=1 keeps the register-staged kernel (bit-identical, tests compare the two)
+        launch_conv1d_f32g(d, n_count, a.B, a.upsample2, st);
     } else if (a.Co > 64) launch_cfg<2, 2, 2, 2>(d, n_count, a.B, st);
     else if (a.Co > 32) launch_cfg<2, 2, 1, 2>(d, n_count, a.B, st);
     else launch_cfg<1, 4, 1, 2>(d, n_count, a.B, st);

@@ -1,0 +1,263 @@
+// DMA-fed exact-fp32 Conv1d / ConvTranspose1d (v_mfma_f32_32x32x2_f32) - its own translation unit because it is built with
+// -mllvm -amdgpu-mfma-vgpr-form (accumulators stay in VGPRs: the asm-pipelined loop below otherwise gets its accumulators copied between
+// VGPRs and AGPRs around every ring step); see versband_amd/build.py.
+#include <type_traits>
+
+#include "conv1d_dev.h"
+#include "lds_asm.h"
+
+template <int I, int N, class F> __device__ __forceinline__ void g_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); g_static_for<I + 1, N>(f); }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DMA-fed exact-fp32 kernel (round 4).  conv1d_f32_kernel above multiplies at 80-93 % of the f32 MFMA rate PER TAP (measured at 8
+// clips: +54 us per tap at 32 channels = 146 TF/s, +114 at 64, +125 at 128) but every layer pays 650-800 us before its first tap and
+// after its last one: the window of every 16-channel chunk goes global -> registers -> transform -> LDS with nothing in flight, weights
+// go through registers once per tap, and the epilogue moves 4-byte lane accesses - the vocoder's 72 ResBlock convolutions spend as long
+// there as in their MFMAs (profiles/r04_open_fp32voc_kernel_stats.csv).  This kernel keeps the arithmetic - same 16-channel chunks,
+// chunk -> tap -> channel-pair order, one v_mfma_f32_32x32x2_f32 per pair: BIT-IDENTICAL results - and changes how operands arrive:
+//   * the raw window of a chunk is DMA'd (global_load_lds, 16 B per lane) into a two-stage LDS ring one chunk ahead; LeakyReLU is applied
+//     to the B fragment after its ds_read (max(v, slope v): one VALU op per 64-cycle MFMA), zero padding by the lanes that own the
+//     out-of-range quads once their own DMA has landed; GroupNorm + swish inputs are pre-activated by gn_apply_kernel (the builder
+//     emits it in fp32 mode: the old kernel redid norm + swish + expf once per output-channel tile, 12x on the 1536-channel layers);
+//   * weight tiles [16 ci][CO_TILE] stream through a 4-stage ring, three tiles in flight, counted vmcnt + one raw s_barrier per tap;
+//   * the [b][co][t] result leaves through the staged 16-byte epilogue of the split-bf16 kernel (conv_epilogue_staged);
+//   * workgroups are numbered so that one XCD keeps a (time tile, clip) unit for ALL its output-channel tiles: the window is fetched
+//     into one L2, the (small) weights into all of them.
+// Conditions (launch_conv1d falls back to conv1d_f32_kernel otherwise): shared or per-clip fp32 weights (16-B aligned), Ci % 16 == 0, Co % 4 == 0, in_act none / LeakyReLU,
+// unit input stride, halo <= 60, 16-byte aligned rows (T_in % 4 == 0) unless the input is upsampled (UPS: 4-byte DMA pieces).
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* g_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* g_glb_ptr_t;
+template <int N> __device__ __forceinline__ void g_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));
+}
+// counted wait in front of ring step t: `ahead` (<= 2) younger weight tiles (+ one window chunk when xin) may stay in flight
+template <int WPW, int XPW> __device__ __forceinline__ void g_wait_tile(int ahead, bool xin) {
+    if (xin) {
+        if (ahead >= 2) g_wait_vmcnt<2 * WPW + XPW>();
+        else if (ahead == 1) g_wait_vmcnt<WPW + XPW>();
+        else g_wait_vmcnt<XPW>();
+    } else {
+        if (ahead >= 2) g_wait_vmcnt<2 * WPW>();
+        else if (ahead == 1) g_wait_vmcnt<WPW>();
+        else g_wait_vmcnt<0>();
+    }
+}
+
+// NSW = weight-tile ring stages (4: three tiles in flight; 3: two - 49 KB of LDS with the 96-sample tile, three workgroups per CU)
+template <int WM, int WN, int TM, int TN, bool UPS, int NSW>
+__global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
+    constexpr int CO_TILE = WM * TM * 32;
+    constexpr int T_TILE = WN * TN * 32;
+    constexpr int XP = (T_TILE + 64 + 63) / 64 * 64;      // window pitch (positions): tile + halo (<= 60) + alignment slack (<= 3)
+    constexpr int NP = XP / 64;
+    constexpr int XST = GK * XP, WT = GK * CO_TILE;       // floats per window stage / weight tile
+    constexpr int NWI = CO_TILE / 16;                     // 1-KB DMA pieces per weight tile
+    constexpr int WPW = NWI >= 4 ? NWI / 4 : 1;           // ... per wave (narrow tiles: the waves repeat each other's pieces)
+    constexpr int XPW = UPS ? 4 * NP : NP;                // window pieces per wave and chunk (16-B lanes: 4 rows of 64 positions per piece)
+    static_assert(NSW == 3 || NSW == 4, "g_wait_tile counts at most two tiles ahead");
+    static_assert(2 * XST * sizeof(float) >= 4 * 32 * CE_PITCH * sizeof(float), "staging patches must fit in the window ring");
+    extern __shared__ __attribute__((aligned(16))) float g_lds[];
+    float* lx = g_lds;
+    float* lw = g_lds + 2 * XST;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    // block -> (channel tile, unit): XCD x = L & 7 serves the units x, x + 8, ... for every channel tile
+    int b, ph, n0, co0;
+    {
+        const int L = blockIdx.x, j = L >> 3;
+        const int ct = j / p.g_tbx, ul = j - ct * p.g_tbx;
+        const int u = ul * 8 + (L & 7);
+        if (u >= p.g_ntb) return;
+        const int z = u / p.g_nt;
+        n0 = (u - z * p.g_nt) * T_TILE;
+        b = z / p.phases; ph = z - b * p.phases;
+        co0 = ct * CO_TILE;
+    }
+    int in_off, out_off, out_stride, n_count;
+    if (p.phases == 1) {
+        in_off = -p.pad; out_off = 0; out_stride = 1; n_count = p.T_out;
+    } else {
+        const int u = p.phases;
+        const int d = p.tr_pad - ph;
+        const int q0 = d > 0 ? (d + u - 1) / u : 0;
+        in_off = q0 - (p.ntaps - 1);
+        out_off = q0 * u + ph - p.tr_pad;
+        out_stride = u;
+        n_count = (p.T_out - out_off + u - 1) / u;
+    }
+    if (n0 >= n_count) return;
+
+    const int T_eff = UPS ? 2 * p.T_in : p.T_in;
+    const int start = n0 + in_off;
+    const int start_al = UPS ? start : (start & ~3);      // 16-B pieces start on a quad of the row (rows are 16-B aligned)
+    const int aoff = start - start_al;
+    const float* xbase = p.x + (int64_t)b * p.x_bstride;
+    const float* wbase = p.w + (int64_t)b * p.w_bstride + (int64_t)ph * p.ntaps * p.Ci * p.Co;      // (w_bstride: per-clip operands, VAE attention)
+    float slope = p.in_act == ACT_LRELU ? p.in_slope : 1.f;            // max(v, 1 v) = v: no branch in the fragment path
+    asm volatile("v_mov_b32 %0, %0" : "+v"(slope));                     // (kept in a VGPR: as an SGPR operand hipcc re-waits lgkmcnt(0) for
+                                                                        //  its s_load in front of every use inside the loop)
+
+    // ---- window DMA: piece i of this wave -> lane's source offset inside the clip (chunk 0) and whether it lies inside [0, T_eff)
+    int xsrc[XPW];
+    unsigned xoob = 0;
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int ii = wave * XPW + i;
+        int ci, pos;
+        if constexpr (UPS) { ci = ii / NP; pos = (ii - ci * NP) * 64 + lane; }
+        else { const int q = ii * 4 + (lane >> 4); ci = q / NP; pos = (q - ci * NP) * 64 + (lane & 15) * 4; }
+        const int idx = start_al + pos;
+        const bool ok = idx >= 0 && idx < T_eff;           // (quads never straddle an end: T_eff % 4 == 0)
+        xsrc[i] = ci * p.T_in + (ok ? (UPS ? (idx >> 1) : idx) : 0);
+        xoob |= ok ? 0u : (1u << i);                       // per lane: a bit per piece
+    }
+    auto issue_x = [&](int ch) {
+        const float* src = xbase + (int64_t)ch * GK * p.T_in;
+        float* dst = lx + (ch & 1) * XST;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int ii = wave * XPW + i;
+            if constexpr (UPS) __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 64), 4, 0, 0);
+            else __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 256), 16, 0, 0);
+        }
+    };
+    auto zero_x = [&](int ch) {          // own pieces only, after the wave's own DMA landed: nobody else writes these bytes
+        float* dst = lx + (ch & 1) * XST;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            if (!((xoob >> i) & 1)) continue;
+            const int ii = wave * XPW + i;
+            if constexpr (UPS) dst[ii * 64 + lane] = 0.f;
+            else *reinterpret_cast<float4*>(dst + ii * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // ---- weight DMA: tile (chunk, tap) = 16 rows of CO_TILE floats, 1-KB pieces of 256 / CO_TILE rows
+    constexpr int RPI = 256 / CO_TILE, LPR = CO_TILE / 4;
+    int wsrc[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int ii = (wave * WPW + i) % NWI;
+        const int row = ii * RPI + lane / LPR;
+        int cog = co0 + (lane % LPR) * 4;
+        if (cog >= p.Co) cog = 0;                           // channels beyond Co: any valid quad, the rows are never stored
+        wsrc[i] = row * p.Co + cog;
+    }
+    auto issue_w = [&](int ch, int j, int slot) {
+        const float* src = wbase + ((int64_t)j * p.Ci + ch * GK) * p.Co;
+        float* dst = lw + slot * WT;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int ii = (wave * WPW + i) % NWI;
+            __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + wsrc[i]), (g_lds_ptr_t)(dst + ii * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = p.Ci / GK;
+    const int total = nchunks * p.ntaps;
+    // prologue: window of chunk 0, then the first NSW - 1 weight tiles (issue order = retirement order)
+    issue_x(0);
+    int nch = 0, nj = 0;                 // tile t + NSW - 1
+#pragma unroll
+    for (int t = 0; t < NSW - 1; ++t) {
+        if (t < total) issue_w(nch, nj, t);
+        if (++nj == p.ntaps) { nj = 0; ++nch; }
+    }
+    int ch = 0, j = 0;                   // tile t = (ch, j)
+    int slot = 0, nslot = NSW - 1;
+    for (int t = 0; t < total; ++t) {
+        const int ahead_all = min(total - 1, t + NSW - 2) - t;
+        if (j == 0) {
+            // the chunk's window must have landed: it was issued in front of tile (t - ntaps + NSW - 1), so at most min(NSW - 2, ntaps)
+            // younger tiles may fly
+            g_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, p.ntaps), false);
+            if (xoob) { zero_x(ch); __builtin_amdgcn_s_waitcnt(0xc07f); }
+        } else {
+            // window ch + 1 was issued at this chunk's first tap, in front of tile (t - j + NSW - 1): younger than tile t while j <= NSW - 2
+            g_wait_tile<WPW, XPW>(ahead_all, ch + 1 < nchunks && j <= NSW - 2);
+        }
+        __builtin_amdgcn_s_barrier();    // tile t (and the window) landed everywhere; everyone finished tile t - 1
+        if (j == 0 && ch + 1 < nchunks) issue_x(ch + 1);
+        if (t + NSW - 1 < total) issue_w(nch, nj, nslot);
+        // fragments are requested two channel pairs ahead of their MFMAs from inline asm with exact lgkmcnt waits (lds_asm.h: with
+        // LDS-DMA in flight hipcc only ever waits lgkmcnt(0), which exposed one LDS round trip per two pairs); three register sets so
+        // that a request never lands in registers an MFMA in flight still reads; LeakyReLU at use, off the load's path
+        const unsigned xaddr = lds_u32(lx + (ch & 1) * XST + aoff + j * p.dil + wn * TN * 32 + l31 + g * XP);
+        const unsigned waddr = lds_u32(lw + slot * WT + wm * TM * 32 + l31 + g * CO_TILE);
+        float a[3][TM], bb[3][TN];
+        auto fload = [&](auto kc) {
+            constexpr int KK = decltype(kc)::value, S = KK % 3;
+            g_static_for<0, TM>([&](auto ic) { constexpr int I = decltype(ic)::value; lds_rd32<(2 * KK * CO_TILE + I * 32) * 4>(a[S][I], waddr); });
+            g_static_for<0, TN>([&](auto jc) { constexpr int J = decltype(jc)::value; lds_rd32<(2 * KK * XP + J * 32) * 4>(bb[S][J], xaddr); });
+        };
+        fload(std::integral_constant<int, 0>{});
+        fload(std::integral_constant<int, 1>{});
+        g_static_for<0, GK / 2>([&](auto kc) {
+            constexpr int KK = decltype(kc)::value, S = KK % 3;
+            if constexpr (KK + 1 < GK / 2) LDS_WAIT(TM + TN); else LDS_WAIT(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) lds_pin(a[S][i]);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) lds_pin(bb[S][jn]);
+            if constexpr (KK + 2 < GK / 2) fload(std::integral_constant<int, KK + 2>{});
+            float bv[TN];
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) bv[jn] = fmaxf(bb[S][jn], bb[S][jn] * slope);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][i], bv[jn], acc[i][jn], 0, 0, 0);
+        });
+        if (++j == p.ntaps) { j = 0; ++ch; }
+        if (++nj == p.ntaps) { nj = 0; ++nch; }
+        if (++slot == NSW) slot = 0;
+        if (++nslot == NSW) nslot = 0;
+    }
+    __syncthreads();                     // the window ring is free: it holds the four wave-private staging patches now
+    if (p.stage_epi) conv_epilogue_staged<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, lx);
+    else conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
+}
+
+template <int WM, int WN, int TM, int TN, bool UPS, int NSW = 4>
+static void launch_cfg_g(ConvDev& d, int n_count, int B, hipStream_t st) {
+    constexpr int CO_TILE = WM * TM * 32, T_TILE = WN * TN * 32, XP = (T_TILE + 64 + 63) / 64 * 64;
+    constexpr int BYTES = (2 * GK * XP + NSW * GK * CO_TILE) * (int)sizeof(float);
+    d.g_nt = cdiv(n_count, T_TILE); d.g_nco = cdiv(d.Co, CO_TILE);
+    d.g_ntb = d.g_nt * B * d.phases; d.g_tbx = cdiv(d.g_ntb, 8);
+    static OnceFlags once;
+    vb_set_max_lds_once(once, (const void*)conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW>, BYTES);
+    hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
+}
+// tile choice of the DMA-fed kernel for wide layers: 128 channels x 128 or 96 samples - whichever leaves the busiest CU fewer samples
+// (the 1536-channel VAE layers at 8 clips: 576 workgroups of 128 samples = 3 on the busiest CU, 768 of 96 = 3 as well, 384 against 288)
+static bool g_prefer_96(int n_count, int Co, int B, int phases) {
+    const int64_t w128 = (int64_t)cdiv(n_count, 128) * cdiv(Co, 128) * B * phases, w96 = (int64_t)cdiv(n_count, 96) * cdiv(Co, 128) * B * phases;
+    return cdiv(w96, 256) * 96 < cdiv(w128, 256) * 128;
+}
+
+// picks the tile and launches; the caller (launch_conv1d) has checked the kernel's conditions
+void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream_t st) {
+    if (upsample2) {
+        if (g_prefer_96(n_count, d.Co, B, d.phases)) launch_cfg_g<4, 1, 1, 3, true, 3>(d, n_count, B, st);
+        else launch_cfg_g<2, 2, 2, 2, true>(d, n_count, B, st);
+    } else if (d.Co > 64) {
+        if (g_prefer_96(n_count, d.Co, B, d.phases)) launch_cfg_g<4, 1, 1, 3, false, 3>(d, n_count, B, st);
+        else launch_cfg_g<2, 2, 2, 2, false>(d, n_count, B, st);
+    } else if (d.Co > 32) launch_cfg_g<2, 2, 1, 2, false>(d, n_count, B, st);
+    else launch_cfg_g<1, 4, 1, 2, false>(d, n_count, B, st);
+}

@@ -45,6 +45,7 @@ static void tune_load() {
     t.final_gemm = getenv("VB_FINAL_GEMM") != nullptr;
     t.router_generic = getenv("VB_ROUTER_GENERIC") != nullptr;
     t.band_epi_old = getenv("VB_BAND_EPI_OLD") != nullptr;
+    t.conv_f32_old = getenv("VB_CONV_F32_OLD") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
@@ -715,6 +716,16 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
         } else if (o.kind == VB_OP_AA_ACT) {
             VB_TRY(launch_aa_act(ptr(o.x), o.gn_gamma, o.gn_beta, o.w, B, o.Ci, tlen(o.x), ptr(o.out), st));
         } else if (o.kind == VB_OP_RESPAIR) {
+            if (!o.w_x3) {
+                // exact-fp32 pair (fp32 vocoder): w / w2_x3 are the fp32 packed [k][Ci][Co] weights of the two convolutions
+                RespairF32Args r;
+                r.x = ptr(o.x); r.out = ptr(o.out); r.B = B; r.C = o.Ci; r.T = tlen(o.x); r.k = o.ksize; r.dil = o.dil;
+                r.w1 = o.w; r.w2 = (const float*)o.w2_x3; r.b1 = o.bias; r.b2 = o.bias2;
+                r.slope = o.in_slope; r.alpha = o.alpha; r.beta = o.beta;
+                if (!r.w1 || !r.w2 || !r.b1 || !r.b2 || tlen(o.out) != r.T) VB_FAIL(VB_E_INVALID, "net op %zu: incomplete fp32 respair", oi);
+                VB_TRY(launch_respair_f32(r, st));
+                continue;
+            }
             RespairArgs r;
             r.x = ptr(o.x); r.out = ptr(o.out); r.B = B; r.C = o.Ci; r.T = tlen(o.x); r.k = o.ksize; r.dil = o.dil;
             r.w1 = (const bf16_t*)o.w_x3; r.w2 = (const bf16_t*)o.w2_x3; r.b1 = o.bias; r.b2 = o.bias2;
@@ -1171,6 +1182,13 @@ int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int 
     a.dil = dil; a.pad = pad; a.in_act = in_act; a.in_slope = in_slope; a.out = out; a.out_bstride = (int64_t)Co * T_out;
     a.T_out = T_out; a.res = res; a.res_bstride = (int64_t)Co * T_out; a.B = B; a.tr_stride = tr_stride; a.tr_pad = tr_pad; a.tr_k = tr_k;
     return launch_conv1d(a, (hipStream_t)stream);
+}
+int vb_respair_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C, int T, int k, int dil,
+                   float slope, float alpha, float beta, float* out, void* stream) {
+    RespairF32Args a;
+    a.x = x; a.out = out; a.B = B; a.C = C; a.T = T; a.k = k; a.dil = dil; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2;
+    a.slope = slope; a.alpha = alpha; a.beta = beta;
+    return launch_respair_f32(a, (hipStream_t)stream);
 }
 int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
                    void* stream) {

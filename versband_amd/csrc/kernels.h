@@ -133,6 +133,14 @@ struct RespairArgs {
     float slope = 0.1f, alpha = 1.f, beta = 0.f;
 };
 int launch_respair(const RespairArgs& a, hipStream_t st);
+// the same pair in exact fp32 (respair_f32.hip; v_mfma_f32_32x32x2_f32, weights fp32 packed [k][Ci][Co]): C = 32 / 64 / 128
+struct RespairF32Args {
+    const float* x = nullptr; float* out = nullptr; int B = 1, C = 0, T = 0, k = 3, dil = 1;
+    const float* w1 = nullptr; const float* w2 = nullptr; const float* b1 = nullptr; const float* b2 = nullptr;
+    float slope = 0.1f, alpha = 1.f, beta = 0.f;
+};
+bool respair_f32_supported(const RespairF32Args& a);
+int launch_respair_f32(const RespairF32Args& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // small kernels

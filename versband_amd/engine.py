@@ -302,7 +302,13 @@ class NetBuilder:
 
     def respair(self, x: int, out: int, ch: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, k: int, dil: int, slope: float,
                 alpha: float, beta: float):
-        """Fused HiFi-GAN ResBlock1 pair (w1/w2 fp32 packed [k][Ci][Co]); narrow stages only (ch = 32 or 64)."""
+        """Fused HiFi-GAN ResBlock1 pair (w1/w2 fp32 packed [k][Ci][Co]); narrow stages only (ch = 32 or 64; fp32 mode: 32 / 64 / 128)."""
+        if self.precision == "fp32":
+            # exact-fp32 pair kernel (respair_f32.hip): the packed fp32 weights go in as they are
+            self.ops.append(L.NetOp(kind=L.OP_RESPAIR, x=x, out=out, res=-1, stats=-1, w_buf=-1, w=self._t(w1), bias=self._t(b1),
+                                    bias2=self._t(b2), Ci=ch, Co=ch, ksize=k, dil=dil, in_slope=slope, alpha=alpha, beta=beta,
+                                    w_x3=None, w2_x3=self._t(w2), ci_pad=ch))
+            return
         p1, c1 = pack.pack_conv_x3(w1.to(self.device))
         p2, c2 = pack.pack_conv_x3(w2.to(self.device))
         assert c1 == ch and c2 == ch
@@ -338,6 +344,13 @@ class NetBuilder:
             # tile of the convolution DMAs its window from there, instead of each tile redoing norm / swish / split while staging
             tmp = self.xt_planes(x, Ci, stats, gamma, beta_gn, in_act, in_slope, upsample2, groups)
             x, stats, gamma, beta_gn, in_act, x_planes = tmp, -1, None, None, L.ACT_NONE, 1
+        if (self.precision == "fp32" and in_act in (L.ACT_GN_SWISH, L.ACT_GN) and stats >= 0 and w is not None and w_buf == -1 and x >= 0
+                and Ci % 16 == 0 and Co % 4 == 0 and in_stride == 1 and tr_stride == 1 and not os.environ.get("VB_FP32_NO_PREPASS")):
+            # exact-fp32 mode: GroupNorm (+ swish) is applied ONCE by gn_apply_kernel and the DMA-fed fp32 kernel (conv1d_f32g_kernel)
+            # reads the activated tensor; the register-staged kernel redid norm + swish + expf for every output-channel tile
+            # (12 times on the 1536-channel layers: 2.3 ms for an 85-GFLOP layer).  VB_FP32_NO_PREPASS=1 keeps the old op list (A/B).
+            tmp = self.gn_apply(x, Ci, stats, gamma, beta_gn, in_act, groups)
+            x, stats, gamma, beta_gn, in_act = tmp, -1, None, None, L.ACT_NONE
         if self.precision == "split" and w is not None and w_buf == -1:
             planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
             self.keep.append(planes)
@@ -568,6 +581,8 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
     """HifiGanGenerator.forward (vocoder/hifigan/modules/hifigan.py:126-143) as an op list; fully
     driven by the vocoder's config.yaml keys."""
     nb = NetBuilder(ctx.device, precision)
+    # exact-fp32 mode: channel counts whose ResBlock1 pairs run fused (respair_f32_kernel); VB_FP32_PAIRS="32,64" / "" for A/B runs
+    fp32_pairs = tuple(int(v) for v in os.environ.get("VB_FP32_PAIRS", "32,64").split(",") if v.strip())
 
     def wt(name):
         if name + ".weight" in sd:
@@ -595,7 +610,8 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
                 last = m == len(rd) - 1
                 dst = xs if last else nb.buf(ch, tm)
                 al, be = (1.0 / nk, 0.0 if j == 0 else 1.0) if last else (1.0, 0.0)
-                if hp["resblock"] == "1" and precision == "split" and ch in fuse_pairs and (rk - 1) * d <= 64 and rk % 2 == 1:
+                fuse = (ch in fuse_pairs and (rk - 1) * d <= 64) if precision == "split" else (ch in fp32_pairs and (rk - 1) * d <= 60 and rk <= 17)
+                if hp["resblock"] == "1" and fuse and rk % 2 == 1:
                     # narrowest, longest stage: both convolutions of the pair in one launch, intermediate kept in LDS
                     # (measured: 645 us per pair against 2 x 600 us at 32 channels; at 64 channels the fused kernel
                     #  fits one workgroup per CU only and loses, 1525 us against 2 x 640 us - so it is not used there)
