@@ -314,6 +314,61 @@ def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
         assert torch.equal(outs[0][0], other[0])
 
 
+def test_small_tile_selection_is_bit_identical(engines, monkeypatch):
+    """The launcher takes 64 x 64 tiles when a launch would make fewer than VB_GEMM_SMALL_TILES (200) tiles of 128 x 128 (one or two
+    clips); VB_GEMM_SMALL=0 keeps the 128 x 128 kernel, VB_GEMM_SMALL_TILES=100000 sends every launch to the small tiles: all three
+    selections must give the same bits (a clip's result must not depend on the batch-driven tile choice)."""
+    eng = engines[(4, "bf16")]
+    T, Lc = 752, 80
+    inp = clip_batch(1, T, Lc)
+    cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+    t_idx = torch.full((2,), 321, dtype=torch.int64)
+    outs = []
+    for env in ({}, {"VB_GEMM_SMALL": "0"}, {"VB_GEMM_SMALL_TILES": "100000"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        L.load().vb_tune_reload()
+        v_, r_ = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
+        torch.cuda.synchronize()
+        outs.append((v_.clone(), r_.clone()))
+        for k in env:
+            monkeypatch.delenv(k)
+    L.load().vb_tune_reload()
+    for other in outs[1:]:
+        assert torch.equal(outs[0][1], other[1]) and torch.equal(outs[0][0], other[0])
+
+
+def test_p8_p16_projections_are_bit_identical(engines, monkeypatch):
+    """Round 4: from two clips up the QKV + RoPE and routed-SwiGLU launches run on the 8-wave 256 x 256 kernel with the P16 column layout
+    (gemm_bf16_p8_kernel<.., 32, 5, 0, 0, 2>); VB_GEMM_P8_OFF=1 keeps the 4-wave 128 x 128 kernels.  Both walk K in the same MFMA order
+    and share the epilogue arithmetic: outputs and routes must be bit-identical, in both precisions - and since one clip (too few tiles
+    for the 8-wave kernel) always takes the 4-wave path, a clip's bits keep not depending on the batch it rides in."""
+    T, Lc = 752, 80
+    t_idx = torch.full((8,), 321, dtype=torch.int64)
+    for prec in ("bf16", "split"):
+        eng = engines[(4, prec)]
+        inp = clip_batch(4, T, Lc)
+        cond = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"], inp["beats"], T)
+        outs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("VB_GEMM_P8_OFF", "1")
+            L.load().vb_tune_reload()
+            v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=11, return_routes=True)
+            torch.cuda.synchronize()
+            outs.append((v.clone(), r.clone()))
+        monkeypatch.delenv("VB_GEMM_P8_OFF")
+        L.load().vb_tune_reload()
+        assert torch.equal(outs[0][1], outs[1][1]), prec
+        assert torch.equal(outs[0][0], outs[1][0]), describe(f"8-wave P16 vs 4-wave projections ({prec})", outs[0][0], outs[1][0])
+        # clip 0 alone (4-wave small tiles) == clip 0 of the batch of four (8-wave kernel)
+        inp1 = clip_batch(1, T, Lc)
+        cond1 = eng.precompute_cond(torch.cat([inp1["t5_cond"], inp1["t5_uncond"]]), inp1["midi"], inp1["beats"], T)
+        v1 = eng.forward(inp1["x_latent"], t_idx[:2], cond1, seed=11)
+        torch.cuda.synchronize()
+        assert torch.equal(v1[0], outs[0][0][0]), f"{prec}: clip 0 depends on its batch"
+
+
 needs_experiments = pytest.mark.skipif(not (torch.cuda.is_available() and L.load().vb_has_experiments()),
                                        reason="kernel exists in the experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build)")
 

@@ -14,7 +14,7 @@ for _ in range(200):
     _w @ _w
 torch.cuda.synchronize()
 shapes = [(12032, 768, 768), (12032, 2304, 768), (24064, 1024, 768), (12032, 768, 512), (12032, 1024, 192), (6016, 768, 768), (6016, 2304, 768)]
-cfgs = ("22", "33", "24", "42", "")
+cfgs = ("22", "33", "")
 if len(sys.argv) > 1 and sys.argv[1] == "small":       # one / two / four clips (x 2 CFG branches): the small-tile configurations
     shapes = [(1504, 768, 768), (1504, 2304, 768), (1504, 1024, 768), (1504, 768, 512), (3008, 768, 768), (3008, 2304, 768),
               (3008, 768, 512), (6016, 768, 768), (6016, 2304, 768)]

@@ -449,8 +449,6 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
                    (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) && !vb_tune().conv_direct_epi) ? 1 : 0;
     if (a.wp && (!a.w_bstride || a.wp_bstride)) {
         if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
-        // VB_CONV_CFG (tuning knob): 1 = wide-T tile (64co x 256t) for 32 < Co <= 64
-        const int cfgv = vb_tune().conv_cfg;
         // one workgroup of the 128co x 256t tile per CU (92 KB LDS): a grid a little over 256 workgroups (every VAE level at
         // B = 8 makes 288) runs as two rounds at 56 % - the 128co x 128t tile (71 KB, two per CU) halves the granule
         const int64_t blocks = (int64_t)cdiv(n_count, 256) * cdiv(a.Co, 128) * a.B * d.phases;
@@ -459,9 +457,8 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
             if (a.Co <= 64) VB_FAIL(VB_E_INVALID, "conv1d: XT input is built for Co > 64 (wide layers)");
             if (eff < 0.7) launch_cfg_xt<2, 2, 2, 1>(d, n_count, a.B, st);
             else launch_cfg_xt<2, 2, 2, 2>(d, n_count, a.B, st);
-        } else if (a.Co > 64 && (eff < 0.7 || cfgv == 3) && cfgv != 2) launch_cfg_x3<2, 2, 2, 1>(d, n_count, a.B, st);
+        } else if (a.Co > 64 && eff < 0.7) launch_cfg_x3<2, 2, 2, 1>(d, n_count, a.B, st);
         else if (a.Co > 64) launch_cfg_x3<2, 2, 2, 2>(d, n_count, a.B, st);
-        else if (a.Co > 32 && cfgv == 1) launch_cfg_x3<2, 2, 1, 4>(d, n_count, a.B, st);
         else if (a.Co > 32) launch_cfg_x3<2, 2, 1, 2>(d, n_count, a.B, st);
         else launch_cfg_x3<1, 4, 1, 2>(d, n_count, a.B, st);
     } else if (!a.wp && a.w_bstride % 4 == 0 && !a.x_bmod && d.in_stride == 1 && (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && a.Ci % GK == 0 &&

@@ -30,7 +30,6 @@ static void tune_load() {
     if (const char* v = getenv("VB_ATTN_DEFER")) t.attn_defer_thr = (float)atof(v);     // log2 units; 0 = exact running maximum
     t.gemm_small = env_int("VB_GEMM_SMALL", 11); t.gemm_small_tiles = env_int("VB_GEMM_SMALL_TILES", 200);
     t.gemm_tile = env_int("VB_GEMM_TILE", -1);
-    t.conv_cfg = env_int("VB_CONV_CFG", 0);
     t.conv_direct_epi = getenv("VB_CONV_DIRECT_EPI") != nullptr;
     t.band_unfused = getenv("VB_BAND_UNFUSED") != nullptr;
     t.w2_pair = env_int("VB_W2_PAIR", 1);
@@ -46,6 +45,7 @@ static void tune_load() {
     t.router_generic = getenv("VB_ROUTER_GENERIC") != nullptr;
     t.band_epi_old = getenv("VB_BAND_EPI_OLD") != nullptr;
     t.conv_f32_old = getenv("VB_CONV_F32_OLD") != nullptr;
+    t.gemm_p8_off = getenv("VB_GEMM_P8_OFF") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels

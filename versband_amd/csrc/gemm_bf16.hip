@@ -26,7 +26,7 @@
 #define BN 128
 #define BK 64
 #define NTHREADS 256
-#define P8_MIN_TILES 96     // (experiments build) selection threshold of the 8-wave 256 x 256 kernel (tiles of the launch)
+#define P8_MIN_TILES 96     // selection threshold of the 8-wave 256 x 256 kernel (tiles of the launch)
 
 struct GemmDev {
     const bf16_t* A; int64_t a_plane; int lda; const int* a_rows; int a_koff_group;
@@ -1373,10 +1373,12 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
     }
 }
 
-// ---- experiments (compiled only with -DVB_EXPERIMENTS: `VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build`; not part of the product
-// library): the 8-wave 256 x 256 kernel, measured slower inside the DiT, kept as the record of the experiment ----
-#ifdef VB_EXPERIMENTS
-// ---- variant 4: 256 x 256 tiles, 8 waves in two staggered groups ("ping-pong") ------------------------------------
+// ---- variant 4: 256 x 256 tiles, 8 waves.  Round 2 measured it slower inside the DiT (quad-layout epilogues) and
+// kept it in the experiments build; with the P16 epilogues of round 3 it wins on the two wide projections (round 4, same box:
+// QKV + RoPE 65.3 -> 60.7 us, whole two-stream run +3.2 %, two clips 56.8 -> 51.8 ms) and the product library instantiates exactly those
+// two forms (software-pipelined schedule, BK 32 x 5 stages, P16 layout: launch_p8_product).  The other schedules / ring shapes /
+// ablations below compile only with -DVB_EXPERIMENTS (`VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build`) ----
+// 256 x 256 tiles, 8 waves in two staggered groups ("ping-pong") ------------------------------------
 // What bounds the 4-wave kernels above is the L2 -> LDS feed (52-60 GB/s per CU whatever the ring, section 5 of DESIGN.md): at
 // 64 flop per byte DMA'd (128^2) or 96 (192^2) the MFMA pipe idles half the time, and with one wave per SIMD every barrier, DMA
 // issue and LDS read of a wave is dead time of its SIMD's matrix pipe.  This kernel
@@ -1644,6 +1646,12 @@ static void launch_p8_v(const GemmDev& d, dim3 grid, hipStream_t st) {
     vb_set_max_lds_once(attr, reinterpret_cast<const void*>(gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), (int)lds);
     hipLaunchKernelGGL((gemm_bf16_p8_kernel<EPI, BKT, NST, PP, ABL, STG>), grid, dim3(512), lds, st, d);
 }
+// product form (tile configuration 89): software-pipelined schedule, BK 32 x 5 stages, P16 column layout - QKV + RoPE and SwiGLU only
+template <int EPI>
+static void launch_p8_product(const GemmDev& d, dim3 grid, hipStream_t st) {
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU) launch_p8_v<EPI, 32, 5, 0, 0, 2>(d, grid, st);
+}
+#ifdef VB_EXPERIMENTS
 #ifndef P8_DEFAULT_BKT
 #define P8_DEFAULT_BKT 32
 #define P8_DEFAULT_NST 5
@@ -2192,11 +2200,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
                    2.0 * npl_ * ((double)a.M * a.K * (a.a_koff_group ? gz_ : 1.0) + (double)a.N * a.K * (a.ngroups > 1 ? a.ngroups : 1)) + ob_, st);
     // tile configuration: 0 = 128x128 (two workgroups per CU), else (TM, TN) of the big-tile kernel (one per CU).  The
     // big tiles are taken when K allows the DMA ring; among them the one that wastes the fewest tile-slots of the last
-    // round of 256 CUs and of partial edge tiles wins.  VB_GEMM_TILE=22|33|24|42 overrides (tuning).
+    // round of 256 CUs and of partial edge tiles wins.  VB_GEMM_TILE=22|33|11|21|23 overrides (the bit-identity
+    // test; the 128 x 256 / 256 x 128 forms 24 / 42 spilled - 576-640 B of scratch at 254-256 VGPRs - and were removed in round 4).
     int cfg = 0;
     if (a.K % 64 == 0) {
         const int forced = vb_tune().gemm_tile;
         if (forced >= 0) {
+            if (forced != 22 && forced != 33 && forced != 11 && forced != 21 && forced != 23) VB_FAIL(VB_E_INVALID, "gemm: VB_GEMM_TILE=%d is not a tile configuration (22, 33, 11, 21, 23)", forced);
             cfg = forced == 22 ? 0 : forced;
             if (cfg == 23 && !(a.epi == EPI_RESID_GATE && !row_groups && a.ngroups <= 1 && a.N % 192 == 0)) cfg = 0;    // 23 serves the plain gated-residual GEMM
         } else {
@@ -2220,6 +2230,18 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             else if (vb_tune().gemm_small && t22 < vb_tune().gemm_small_tiles && !(a.group_rows > 0 && a.ngroups >= 8 && a.ngroups % 8 == 0 && !vb_tune().no_xcd_groups))
                 cfg = vb_tune().gemm_small;
         }
+    }
+    // 8-wave 256 x 256 kernel with the P16 epilogues (round 4) on the two wide projections - QKV + RoPE and the routed SwiGLU - whenever the
+    // launch makes at least P8_MIN_TILES of its tiles (two clips and up; one clip keeps the small tiles) and the P16 layout applies (the
+    // conditions of the 4-wave P16 forms).  Same k order, same epilogue arithmetic: bit-identical to the 4-wave kernels
+    // (VB_GEMM_P8_OFF=1 keeps those; test_p8_p16_projections_are_bit_identical), so a clip's bits still do not depend on its batch.
+    if ((a.epi == EPI_QKV_ROPE || a.epi == EPI_SWIGLU) && a.K % 64 == 0 && a.N % 16 == 0 && vb_tune().gemm_tile < 0 && !vb_tune().gemm_p8_off &&
+        !vb_tune().qkv_p16_off && a.conv_ci == 0 && a.group_rows == 0) {
+        const int gz = row_groups ? 1 : (a.ngroups > 0 ? a.ngroups : 1);
+        const int64_t t88 = (int64_t)(row_groups ? (cdiv(a.M, 256) + a.ngroups) : cdiv(a.M, 256)) * cdiv(a.N, 256) * gz;
+        const bool lay = a.epi == EPI_QKV_ROPE ? (d.hd % 16 == 0 && d.D % 16 == 0 && !a.group_off && a.ngroups <= 1)
+                                               : (a.ldc % 8 == 0 && a.c_noff_group % 8 == 0);
+        if (lay && t88 >= P8_MIN_TILES) cfg = 89;
     }
 #ifdef VB_EXPERIMENTS
     // 8-wave 256 x 256 kernel (variant 4): taken when the problem makes enough of its tiles to occupy a good part of the chip - it
@@ -2282,9 +2304,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 #define VB_GEMM_CASE(E) \
         case E: \
             if (cfg == 88) { VB_P8_LAUNCH(E) } \
+            else if (cfg == 89) launch_p8_product<E>(d, grid, st); \
             else if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
-            else if (cfg == 24) launch_big<E, 2, 4, 3>(d, grid, st); \
-            else if (cfg == 42) launch_big<E, 4, 2, 3>(d, grid, st); \
             else if (cfg == 11) launch_big<E, 1, 1, 3>(d, grid, st); \
             else if (cfg == 21) launch_big<E, 2, 1, 3>(d, grid, st); \
             else launch_t<E>(d, grid, st); \

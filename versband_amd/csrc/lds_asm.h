@@ -14,6 +14,7 @@
 // ordered) wait.  LDS operations of one wave return in order, so "N younger ones in flight" is exact.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
 
 __device__ __forceinline__ unsigned lds_u32(const void* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -24,3 +25,14 @@ template <int OFF> __device__ __forceinline__ void lds_rd32(float& v, unsigned a
 }
 #define LDS_WAIT(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N))
 __device__ __forceinline__ void lds_pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// 16-byte form (bf16 MFMA fragments)
+typedef unsigned lds_u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ void lds_rd128(lds_u32x4& v, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is 16 bits");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_pin(lds_u32x4& v) { asm volatile("" : "+v"(v)); }
+template <int I, int N, class F> __device__ __forceinline__ void lds_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); lds_static_for<I + 1, N>(f); }
+}
