@@ -293,26 +293,6 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def broadcast_state(sds, rank, world, device):
-    """rank 0's checkpoints -> every rank, one flat RCCL broadcast (the only collective of the path)."""
-    import torch.distributed as dist
-    flat_keys = [(i, k) for i, sd in enumerate(sds) for k in sd]
-    sizes = [sds[i][k].numel() for i, k in flat_keys]
-    buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-    if rank == 0:
-        off = 0
-        for (i, k), n in zip(flat_keys, sizes):
-            buf[off:off + n].copy_(sds[i][k].reshape(-1))
-            off += n
-    dist.broadcast(buf, src=0)
-    off = 0
-    out = [dict() for _ in sds]
-    for (i, k), n in zip(flat_keys, sizes):
-        out[i][k] = buf[off:off + n].view(sds[i][k].shape)
-        off += n
-    return out
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
 # ------------------------------------------------------------------------------------------------------------------
@@ -503,20 +483,18 @@ def main():
     if not long:
         assert T_lat <= dcfg.max_len, f"{args.seconds} s = {T_lat} latent frames exceeds max_len {dcfg.max_len}: use --workload c5"
     shapes = [synth.dit_shapes(dcfg), synth.vae_decoder_shapes(vcfg), synth.hifigan_shapes(hcfg)]
-    if rank == 0:
-        sds = [synth.make_state_dict(s, SEED + i) for i, s in enumerate(shapes)]
-    else:
-        sds = [{k: torch.empty(shp) for k, (shp, _) in s.items()} for s in shapes]
+    sds = [synth.make_state_dict(s, SEED + i) for i, s in enumerate(shapes)] if rank == 0 else None
     bcast_ms, bcast_bytes = None, 0
     if world > 1:
         import torch.distributed as dist
+        from versband_amd import dist as vdist
         torch.cuda.synchronize()
         dist.barrier()
-        t0 = time.perf_counter()
-        sds = broadcast_state(sds, rank, world, device)
-        torch.cuda.synchronize()
-        bcast_ms = 1e3 * (time.perf_counter() - t0)
-        bcast_bytes = 4 * sum(v.numel() for sd in sds for v in sd.values())
+        # the one collective of the path (product code: versband_amd/dist.py, also used by scripts/test_final.py --num_gpus N):
+        # rank 0's checkpoints as ONE flat fp32 broadcast, every rank's received bytes compared
+        sds, binfo = vdist.broadcast_state(sds, 0, device)
+        assert binfo["checked"] and binfo["buffers"] == 1
+        bcast_ms, bcast_bytes = binfo["ms"], binfo["bytes"]
         seen = torch.ones(1, device=device)
         dist.all_reduce(seen)                      # every rank reports in over the data-path backend (RCCL unless one-device test)
         assert int(seen.item()) == world

@@ -4,7 +4,8 @@
 Keeps the CLI and the semantics of the reference's scripts/test_final.py (flags :34-98, per-item loop
 :376-457, output naming :429-457, clap.csv :462) without its defects: `--ddim_steps`
 really sets the number of Euler steps, `x_T` really is the start latent, no hard-coded paths.
-One process per GPU (`--num_gpus`, items sharded rank::world like DistributedSampler); no collective.
+One process per GPU (`--num_gpus`, items sharded rank::world like DistributedSampler); the only collective is the broadcast of
+rank 0's checkpoints (versband_amd/dist.py: RCCL over xGMI) - the reference has every rank read them from disk (:351-357, 467-477).
 
 `--synthetic N` runs N seeded synthetic items with random-init checkpoints (no dataset / checkpoint needed).
 """
@@ -23,6 +24,7 @@ if ROOT not in sys.path:
 
 from ldm.models.diffusion.cfm1_audio_sampler import CFMSampler  # noqa: E402
 from ldm.util import instantiate_from_config  # noqa: E402
+from versband_amd import dist as vdist  # noqa: E402
 from versband_amd import synth  # noqa: E402
 from versband_amd.harness import (MEL_DOWNSAMPLE, UNIT_FRAMES_MULTIPLE, InferDataset, read_wav, safe_path,  # noqa: E402,F401
                                   save_rows_to_tsv, write_wav_pcm16)
@@ -46,6 +48,7 @@ def parse_args():
     p.add_argument("--save_dir", type=str, default="test")
     p.add_argument("--save_plot", action="store_true")
     p.add_argument("--num_gpus", type=int, default=1)
+    p.add_argument("--master_port", type=int, default=54189, help="rendezvous port of the process group (the reference's tcp://localhost:54189)")
     p.add_argument("--sample_rate", type=int, default=24000)
     p.add_argument("--synthetic", type=int, default=0, help="run N synthetic items with random-init checkpoints")
     p.add_argument("--synthetic_frames", type=int, default=1500)
@@ -74,34 +77,53 @@ class SyntheticDataset:
                 "beats": c["beats"], "acoustic": torch.zeros(20, T_mel), "audio_path": None, "clip": i}
 
 
-def initialize_model(args, device):
+def initialize_model(args, device, rank=0):
     config = load_config(args.config)
     config.model.params["precision"] = args.precision
     if args.dummy_text:
         config.model.params["cond_stage_config"]["params"]["dummy_text"] = True
     model = instantiate_from_config(config.model)
-    if args.ckpt:
-        sd = torch.load(args.ckpt, map_location="cpu")["state_dict"]
-    else:       # random-init checkpoint of the configured architecture
-        dcfg = model.model.diffusion_model.cfg
-        sd = {"model.diffusion_model." + k: v for k, v in synth.make_state_dict(synth.dit_shapes(dcfg), args.seed).items()}
-        sd.update({"first_stage_model." + k: v for k, v in
-                   synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), args.seed + 1).items()})
+    sd = None
+    if rank == 0:           # rank 0 reads (or draws) the checkpoint; the other ranks receive it (one flat broadcast, bitwise checked)
+        if args.ckpt:
+            sd = torch.load(args.ckpt, map_location="cpu")["state_dict"]
+        else:       # random-init checkpoint of the configured architecture
+            dcfg = model.model.diffusion_model.cfg
+            sd = {"model.diffusion_model." + k: v for k, v in synth.make_state_dict(synth.dit_shapes(dcfg), args.seed).items()}
+            sd.update({"first_stage_model." + k: v for k, v in
+                       synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), args.seed + 1).items()})
+    sd, info = vdist.broadcast_state(sd, 0, device)
+    if info["bytes"]:
+        print(f"[rank {rank}] model weights by broadcast: {info['bytes'] / 1e6:.0f} MB in {info['ms']:.1f} ms over {info['backend']}, "
+              f"bitwise check {'passed' if info['checked'] else 'skipped'}")
     model.load_state_dict(sd, strict=False)
     model = model.to(device)
     return CFMSampler(model, num_timesteps=1000)
 
 
-def make_vocoder(args, device, tmp_dir):
-    if args.vocoder_ckpt:
-        return HifiGAN(vocoder_ckpt=args.vocoder_ckpt, device=device)
-    import yaml
-    hcfg = synth.HifiGanConfig()
-    os.makedirs(tmp_dir, exist_ok=True)
-    yaml.safe_dump(hcfg.as_hparams(), open(os.path.join(tmp_dir, "config.yaml"), "w"))
-    torch.save({"state_dict": {"model_gen": synth.make_state_dict(synth.hifigan_shapes(hcfg), args.seed + 2)}},
-               os.path.join(tmp_dir, "model_ckpt_steps_0.ckpt"))
-    return HifiGAN(vocoder_ckpt=tmp_dir, device=device)
+def make_vocoder(args, device, tmp_dir, rank=0):
+    """HifiGAN(vocoder_ckpt=dir, device) as the reference builds it (scripts/test_final.py:361) on rank 0 / single process; with several
+    ranks the config and the `model_gen` weights of rank 0 travel by broadcast and the wrapper is built from them."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    voc = None
+    if rank == 0:
+        if args.vocoder_ckpt:
+            voc = HifiGAN(vocoder_ckpt=args.vocoder_ckpt, device=device)
+        else:
+            import yaml
+            hcfg = synth.HifiGanConfig()
+            os.makedirs(tmp_dir, exist_ok=True)
+            yaml.safe_dump(hcfg.as_hparams(), open(os.path.join(tmp_dir, "config.yaml"), "w"))
+            torch.save({"state_dict": {"model_gen": synth.make_state_dict(synth.hifigan_shapes(hcfg), args.seed + 2)}},
+                       os.path.join(tmp_dir, "model_ckpt_steps_0.ckpt"))
+            voc = HifiGAN(vocoder_ckpt=tmp_dir, device=device)
+    if not multi:
+        return voc
+    box = [dict(voc.config) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    state, _ = vdist.broadcast_state(voc.state if rank == 0 else None, 0, device)
+    return voc if rank == 0 else HifiGAN.from_state(box[0], state, device)
 
 
 def _mono(a):
@@ -124,12 +146,14 @@ def _load_ground_truth(item):
 
 @torch.no_grad()
 def gen_song(rank, args):
-    device = torch.device(f"cuda:{int(rank)}")
+    device = torch.device("cuda:0" if vdist.one_device() else f"cuda:{int(rank)}")     # (VB_ONE_DEVICE: functional test of N > 1 on one GPU)
+    torch.cuda.set_device(device)
+    vdist.init(rank, args.num_gpus, device, master_port=args.master_port)
     dataset = SyntheticDataset(args.synthetic, args.synthetic_frames, args.seed) if args.synthetic else \
         InferDataset(args.manifest_path, args.other_condition, seed=args.seed)
-    indices = list(range(len(dataset)))[rank::args.num_gpus]          # DistributedSampler(shuffle=False) sharding
-    sampler = initialize_model(args, device)
-    vocoder = make_vocoder(args, device, os.path.join(args.save_dir, f".synthetic_vocoder_{rank}"))
+    indices = vdist.shard_indices(len(dataset), rank, args.num_gpus)  # DistributedSampler(shuffle=False) sharding
+    sampler = initialize_model(args, device, rank)
+    vocoder = make_vocoder(args, device, os.path.join(args.save_dir, f".synthetic_vocoder_{rank}"), rank)
     mel_net = None
     if args.eval_mel:
         from preprocess.NAT_mel import MelNet
@@ -195,6 +219,10 @@ def gen_song(rank, args):
         save_rows_to_tsv(mel_rows, ["name", "scale", "sample", "mel_l1_vs_decoded", "mel_l1_vs_gt_accomp"],
                          os.path.join(args.save_dir, f"mel_l1{tag}.tsv"))
     print(f"[rank {rank}] wrote {len(rows)} generated clips, {csv_path}")
+    if args.num_gpus > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -24,18 +24,21 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import bench
     from tests.helpers import clip_batch
     from versband_amd import synth
     shapes = [synth.hifigan_shapes(synth.HifiGanConfig(upsample_initial_channel=32)),
               {"a.weight": ((3, 5), ("u", 1.0)), "b.bias": ((7,), ("norm",))}]
+    from versband_amd import dist as vdist
+    sds = [synth.make_state_dict(s, 11 + i) for i, s in enumerate(shapes)] if rank == 0 else None
     if rank == 0:
-        sds = [synth.make_state_dict(s, 11 + i) for i, s in enumerate(shapes)]
-    else:
-        sds = [{k: torch.empty(shp) for k, (shp, _) in s.items()} for s in shapes]
-    got = bench.broadcast_state(sds, rank, world, torch.device("cpu"))
+        sds[1]["steps"] = torch.tensor([7, 9], dtype=torch.int64)      # a non-fp32 entry rides in its own flat buffer
+    got, info = vdist.broadcast_state(sds, 0, torch.device("cpu"))
     ref = [synth.make_state_dict(s, 11 + i) for i, s in enumerate(shapes)]
     ok = all(torch.equal(got[i][k], ref[i][k]) for i in range(2) for k in ref[i])
+    ok = ok and info["checked"] and info["buffers"] == 2 and torch.equal(got[1]["steps"], torch.tensor([7, 9]))
+    ok = ok and vdist.shard_indices(5, rank, world) == ([0, 2, 4] if rank == 0 else [1, 3])
+    single, _ = vdist.broadcast_state({"w": torch.full((3,), 2.5)} if rank == 0 else None, 0, torch.device("cpu"))     # one dict in, one dict out
+    ok = ok and torch.equal(single["w"], torch.full((3,), 2.5))
     # clip sharding: rank r owns global clips [r*B, (r+1)*B)
     B, T = 2, 8
     mine = clip_batch(B, T, 4, clip0=rank * B)

@@ -505,6 +505,18 @@ class HifiGAN:
         self._net = None
         self._ctx = None
 
+    @classmethod
+    def from_state(cls, config: dict, state: dict, device=None) -> "HifiGAN":
+        """the generator from an already loaded config + `model_gen` state dict (multi-GPU runs: rank 0 reads <vocoder_ckpt> and the
+        weights reach the other ranks through versband_amd.dist.broadcast_state instead of N disk reads)"""
+        self = cls.__new__(cls)
+        self.config = dict(config)
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.state = state
+        self._net = None
+        self._ctx = None
+        return self
+
     def net(self):
         from .engine import Context, build_hifigan
         if self._net is None:
