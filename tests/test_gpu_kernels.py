@@ -465,3 +465,23 @@ def test_fp32_vocoder_fused_pairs_equal_unfused_launches(lib, monkeypatch):
     assert torch.isfinite(fused).all()
     assert torch.equal(unfused, old), f"DMA-fed vs register-staged vocoder differ by {float((unfused - old).abs().max()):.3e}"
     assert torch.equal(fused, unfused), f"fused pairs vs unfused differ by {float((fused - unfused).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("B,Ci,T,k,dil,act", [(2, 32, 1000, 7, 1, 1), (1, 32, 1541, 7, 1, 1), (1, 80, 300, 5, 3, 0), (3, 16, 64, 1, 1, 0)])
+def test_one_output_channel_conv_is_bit_identical_to_the_mfma_kernel(lib, monkeypatch, B, Ci, T, k, dil, act):
+    """conv1d_co1_kernel (HiFi-GAN conv_post: one output channel) runs the fmaf chain of v_mfma_f32_32x32x2_f32 on the vector ALU in the
+    same chunk -> tap -> channel order: same bits as the MFMA kernel it replaces (VB_CONV_F32_OLD=1), incl. lengths that are not a
+    multiple of anything and a channel count that is not a multiple of the 16-channel chunk."""
+    x, w, b = dev(rnd((B, Ci, T), "ox")), rnd((1, Ci, k), "ow", 1.0 / (Ci * k) ** 0.5), dev(rnd((1,), "ob"))
+    pad = (k - 1) * dil // 2
+    wpk = dev(pack.pack_conv(w))
+    new = _conv_f32(lib, x, wpk, b, None, B, Ci, T, 1, k, dil, pad, act)
+    monkeypatch.setenv("VB_CONV_F32_OLD", "1")
+    lib.vb_tune_reload()
+    old = _conv_f32(lib, x, wpk, b, None, B, Ci, T, 1, k, dil, pad, act)
+    monkeypatch.delenv("VB_CONV_F32_OLD")
+    lib.vb_tune_reload()
+    assert torch.isfinite(new).all() and torch.equal(new, old), f"VALU vs MFMA one-channel conv differ by {float((new - old).abs().max()):.3e}"
+    xin = F.leaky_relu(x.double().cpu(), 0.1) if act else x.double().cpu()
+    ref = F.conv1d(xin, w.double(), b.double().cpu(), dilation=dil, padding=pad)
+    assert rel_l2(new, ref) < 2e-6

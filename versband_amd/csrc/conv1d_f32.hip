@@ -396,6 +396,55 @@ static void launch_cfg_xt(const ConvDev& d, int n_count, int B, hipStream_t st) 
     hipLaunchKernelGGL((conv1d_x3_kernel<WM, WN, TM, TN, 5>), grid, dim3(256), 0, st, d);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// One output channel (HiFi-GAN conv_post: 32 -> 1 channels, k = 7, tanh; vocoder/hifigan/modules/hifigan.py:139-141).  On the MFMA kernels a
+// 32-row tile computes one useful row: 860 us for 0.86 GFLOP at 8 clips.  Here a thread owns two output samples and runs the SAME fmaf
+// chain the f32 MFMA does (16-channel chunks -> taps -> channels; v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, bit for bit), on the
+// activated window staged once per chunk in LDS: bit-identical to conv1d_f32_kernel, exact fp32 in both vocoder precisions.
+// ---------------------------------------------------------------------------------------------------------
+#define C1_TT 512
+__global__ void __launch_bounds__(256) conv1d_co1_kernel(const ConvDev p) {
+    __shared__ float xs[CK][C1_TT + XHALO];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, n0 = blockIdx.x * C1_TT;
+    const int halo = (p.ntaps - 1) * p.dil, xw = C1_TT + halo;
+    const float* xb = p.x + (int64_t)b * p.x_bstride;
+    float acc[2] = {0.f, 0.f};
+    for (int c0 = 0; c0 < p.Ci; c0 += CK) {
+        for (int i = tid; i < CK * xw; i += 256) {
+            const int ci = i / xw, wpos = i - ci * xw;
+            const int idx = n0 - p.pad + wpos;
+            float v = 0.f;
+            if (c0 + ci < p.Ci && idx >= 0 && idx < p.T_in) {
+                v = xb[(int64_t)(c0 + ci) * p.T_in + idx];
+                if (p.in_act == ACT_LRELU) v = v > 0.f ? v : v * p.in_slope;
+            }
+            xs[ci][wpos] = v;
+        }
+        __syncthreads();
+        for (int j = 0; j < p.ntaps; ++j) {
+            const float* wj = p.w + (int64_t)j * p.Ci + c0;
+#pragma unroll
+            for (int ci = 0; ci < CK; ++ci) {
+                const float wv = (c0 + ci < p.Ci) ? wj[ci] : 0.f;
+                acc[0] = fmaf(wv, xs[ci][2 * tid + j * p.dil], acc[0]);
+                acc[1] = fmaf(wv, xs[ci][2 * tid + 1 + j * p.dil], acc[1]);
+            }
+        }
+        __syncthreads();
+    }
+    const float bias = p.bias ? p.bias[0] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int n = n0 + 2 * tid + e;
+        if (n >= p.T_out) continue;
+        const int64_t oi = (int64_t)b * p.out_bstride + n;
+        const float res = p.res ? p.res[(int64_t)b * p.res_bstride + n] : 0.f;
+        const float old = p.beta != 0.f ? p.out[oi] : 0.f;
+        p.out[oi] = conv_out_value(p, acc[e], bias, res, old);
+    }
+}
+
 int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     ConvDev d;
     d.x = a.x; d.x_bstride = a.x_bstride; d.Ci = a.Ci; d.T_in = a.T_in; d.x_bmod = a.x_bmod;
@@ -447,7 +496,10 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     d.stage_epi = (a.tr_stride <= 1 && !a.out_transposed && a.T_out % 4 == 0 && a.out_bstride % 4 == 0 &&
                    (!a.res || a.res_bstride % 4 == 0) && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                    (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) && !vb_tune().conv_direct_epi) ? 1 : 0;
-    if (a.wp && (!a.w_bstride || a.wp_bstride)) {
+    if (a.Co == 1 && a.w && !a.w_bstride && !a.x_bmod && d.phases == 1 && d.in_stride == 1 && !a.upsample2 && !a.out_transposed &&
+        (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && !vb_tune().conv_f32_old) {
+        hipLaunchKernelGGL(conv1d_co1_kernel, dim3(cdiv(a.T_out, C1_TT), a.B), dim3(256), 0, st, d);       // (VB_CONV_F32_OLD=1: the MFMA kernels)
+    } else if (a.wp && (!a.w_bstride || a.wp_bstride)) {
         if (a.Ci_pad % CK3) VB_FAIL(VB_E_INVALID, "conv1d: split weights need Ci_pad %% %d == 0", CK3);
         // one workgroup of the 128co x 256t tile per CU (92 KB LDS): a grid a little over 256 workgroups (every VAE level at
         // B = 8 makes 288) runs as two rounds at 56 % - the 128co x 128t tile (71 KB, two per CU) halves the granule
