@@ -35,7 +35,12 @@ MEL_HPARAMS = dict(fft_size=1280, audio_num_mel_bins=80, audio_sample_rate=24000
 
 
 def parse_args():
-    p = argparse.ArgumentParser()
+    p = argparse.ArgumentParser(
+        description="AccompBand inference on the MI355X-native engine (the reference's scripts/test_final.py CLI).",
+        epilog="Captions of manifest items: the 'Musical:' sentence is composed by versband_amd.harness.CaptionGenerator2 from the same decision "
+               "rules as the reference's caption generator (key / tempo / pitch / duration classes, confidence gates) but NOT with its ~25 tables of "
+               "English templates - the wording is not the reference's, so with a trained T5-conditioned checkpoint the text conditioning differs "
+               "from the reference's for the same item.  Pass precomputed captions / embeddings in the manifest to reproduce a reference run.")
     p.add_argument("--config", type=str, default=os.path.join(ROOT, "configs", "vocal2music.yaml"))
     p.add_argument("--ckpt", type=str, default=None)
     p.add_argument("--vocoder_ckpt", type=str, default=None)
@@ -151,6 +156,8 @@ def gen_song(rank, args):
     vdist.init(rank, args.num_gpus, device, master_port=args.master_port)
     dataset = SyntheticDataset(args.synthetic, args.synthetic_frames, args.seed) if args.synthetic else \
         InferDataset(args.manifest_path, args.other_condition, seed=args.seed)
+    if rank == 0 and not args.synthetic:
+        print("note: 'Musical:' caption sentences come from versband_amd.harness.CaptionGenerator2 - same facts, NOT the reference's wording (see --help)")
     indices = vdist.shard_indices(len(dataset), rank, args.num_gpus)  # DistributedSampler(shuffle=False) sharding
     sampler = initialize_model(args, device, rank)
     vocoder = make_vocoder(args, device, os.path.join(args.save_dir, f".synthetic_vocoder_{rank}"), rank)
