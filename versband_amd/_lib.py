@@ -150,6 +150,8 @@ def load(build_if_missing: bool = True):
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
+        if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            raise VersbandError(f"{LIB_PATH} is missing and hipcc is not available to build it")
         build()
     elif sources_present():
         # never run a binary built from other sources than the ones on disk: an ABI struct mismatch would be memory corruption, not an

@@ -479,7 +479,8 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
     if (a.xt && a.wp && a.Co >= 384 && a.Ci % 64 == 0 && a.Ci_pad == a.Ci && a.Co % 4 == 0 && d.phases == 1 && !a.wp_bstride && !a.w_bstride &&
         a.alpha == 1.f && a.beta == 0.f && a.acc_scale == 1.f && a.out_act == ACT_NONE && !a.out_transposed && !a.add &&
         a.out_bstride == (int64_t)a.Co * a.T_out && (!a.res || a.res_bstride == a.out_bstride) &&
-        a.T_out == (a.upsample2 ? 2 * a.T_in : a.T_in) && !vb_tune().conv_gemm_off) {
+        a.T_out == (a.upsample2 ? 2 * a.T_in : a.T_in) && (int64_t)a.B * a.T_out < (1 << 21) && a.Co < (1 << 21) && !vb_tune().conv_gemm_off) {
+        // (B * T_out / Co beyond launch_gemm's reciprocal-divide range fall through to the conv kernels - ADVICE r3)
         GemmArgs g;
         g.A = a.xt; g.a_plane = d.xt_plane; g.lda = a.Ci; g.B = a.wp; g.b_plane = a.wp_plane; g.ldb = a.Ci_pad;
         g.M = a.B * a.T_out; g.N = a.Co; g.K = d.ntaps * a.Ci; g.nseg = 3; g.ngroups = a.B;

@@ -249,13 +249,19 @@ int launch_mean_rows(const float* x, int B, int L, int D, float* out, hipStream_
 // stem helpers (vocal2music_moe.py:388-393)
 // ---------------------------------------------------------------------------
 // out[b][d][t] = table[idx[b][t]][d]
-__global__ void embed_t_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table, int B, int T, int D, float* out) {
+__global__ void embed_t_kernel(const int64_t* __restrict__ idx, const float* __restrict__ table, int B, int T, int D, int vocab, float* out) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, t0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 64 x 4
     for (int i = ty; i < 64; i += 4) {
         int t = t0 + i;
-        if (t < T && d0 + tx < D) tile[i][tx] = table[idx[(int64_t)b * T + t] * D + d0 + tx];
+        if (t < T && d0 + tx < D) {
+            //  the host range-checks index tensors once per identity; the read itself is clamped so that a buffer refilled behind
+            // that cache (raw pointer writes, DLPack aliases) can never index outside the table
+            int64_t ix = idx[(int64_t)b * T + t];
+            ix = ix < 0 ? 0 : (ix >= vocab ? vocab - 1 : ix);
+            tile[i][tx] = table[ix * D + d0 + tx];
+        }
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
@@ -263,8 +269,8 @@ __global__ void embed_t_kernel(const int64_t* __restrict__ idx, const float* __r
         if (d < D && t < T) out[((int64_t)b * D + d) * T + t] = tile[tx][i];
     }
 }
-int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(embed_t_kernel, dim3(cdiv(T, 64), cdiv(D, 64), B), dim3(256), 0, st, idx, table, B, T, D, out);
+int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, int vocab, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(embed_t_kernel, dim3(cdiv(T, 64), cdiv(D, 64), B), dim3(256), 0, st, idx, table, B, T, D, vocab, out);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }

@@ -333,7 +333,7 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
     // ---- acoustic stem (vocal2music_moe.py:388-393)
     ConvArgs cv;
     for (int which = 0; which < 2; ++which) {
-        VB_TRY(launch_embed_t(which ? beats : midi, which ? w.beats_emb : w.midi_emb, B, T_mel, D, s.tA, st));
+        VB_TRY(launch_embed_t(which ? beats : midi, which ? w.beats_emb : w.midi_emb, B, T_mel, D, which ? 3 : 130, s.tA, st));   // Embedding(3) / Embedding(130), vocal2music_moe.py:337-350
         cv = ConvArgs();
         cv.x = s.tA; cv.x_bstride = (int64_t)D * T_mel; cv.Ci = D; cv.T_in = T_mel;
         cv.w = which ? w.beats_conv_w : w.midi_conv_w; cv.bias = which ? w.beats_conv_b : w.midi_conv_b;

@@ -722,7 +722,7 @@ gemm_bf16_glds_kernel(const GemmDev p) {
     const int total = KT * p.nseg;
     // QKV, P16: a tile of the V third exchanges the operands' roles (see wave_epilogue_vt_p16) - the permutation then belongs to the TOKEN rows
     bool vsec = false;
-    if constexpr (P16 && EPI == EPI_QKV_ROPE) vsec = n0 >= 2 * p.D && (p.T & 15) == 0 && !p.no_vt16;
+    if constexpr (P16 && EPI == EPI_QKV_ROPE) vsec = n0 >= 2 * p.D && (p.T & 15) == 0 && (p.Tpad & 7) == 0 && !p.no_vt16;       // (16-byte V^T stores: T and the padded pitch)
 
     const bf16_t* asrc[SPW]; const bf16_t* bsrc[SPW];
 #pragma unroll
@@ -2290,6 +2290,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         d.grp_xcd = (a.conv_ci == 0 && a.ngroups % 8 == 0 && !vb_tune().no_xcd_groups) ? 1 : 0;
         mt = d.grp_xcd ? a.ngroups * d.grp_tiles : (a.ngroups * d.grp_tiles + 7) / 8 * 8;
     }
+    //  uniform groups described only by group_rows must have been taken up above: on any other route (K % 32 != 0 -> the
+    // register-staged kernel) every row would silently run against group 0's operand
+    if (a.group_rows > 0 && !a.group_off && d.grp_rows == 0) VB_FAIL(VB_E_INVALID, "gemm: uniform row groups need K %% 32 == 0 (K=%d)", a.K);
     dim3 grid(d.n_tiles * ((mt + 7) / 8 * 8), 1, row_groups ? 1 : (a.ngroups > 0 ? a.ngroups : 1));
     d.ncc = 0; d.rpx = (mt + 7) / 8;
     if (!cfg && !row_groups) {       // VB_GEMM_NCHUNK=c (tuning, default off until measured in the pipeline): column chunking for wide N

@@ -178,7 +178,7 @@ int launch_gemv_rows_idx(const float* x, int x_ld, const int64_t* idx, const flo
                          const float* bias, int R, int N, int K, int act_in, float* out, int out_ld, hipStream_t st, int sin_rows = 0);
 // (sin_rows > 0: x is the timestep-sinusoid table with that many rows; indices outside it are evaluated on the fly)
 int launch_mean_rows(const float* x, int B, int L, int D, float* out, hipStream_t st);
-int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, float* out, hipStream_t st);
+int launch_embed_t(const int64_t* idx, const float* table, int B, int T, int D, int vocab, float* out, hipStream_t st);   // (indices clamped to [0, vocab))
 int launch_pool_add(const float* a, const float* b, int B, int C, int T_in, float* out, hipStream_t st);
 int launch_transpose_bct_btc(const float* in, int B, int C, int T_in, int T_out, float* out, hipStream_t st);
 int launch_final_layer(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,

@@ -10,8 +10,9 @@
 // (192 flop per 12 bytes at 32 channels) and every layer pays its staging / epilogue once more.  Here one workgroup produces
 // TT = 128 - (k-1) output samples of ALL channels and the intermediate never leaves LDS:
 //   * conv1: the raw window of x (128 + (k-1) d positions) arrives by DMA (global_load_lds, 16-B lanes) one 16-channel chunk ahead, the
-//     weight tiles [16 ci][C co] of BOTH convolutions stream through one 4-stage ring (three tiles in flight, counted vmcnt, one raw
-//     s_barrier per tap); LeakyReLU is applied to the B fragment after its ds_read; a wave owns 32 intermediate positions x all channels;
+//     weight tiles [TPS taps][16 ci][C co] of BOTH convolutions stream through one 3- or 4-stage ring (counted vmcnt, one raw s_barrier per
+//     ring step = TPS taps of a chunk: 32 MFMAs per wave); fragments by inline-asm ds_read_b32 two channel pairs ahead with exact lgkmcnt
+//     (lds_asm.h); LeakyReLU is applied to the B fragment after its read; a wave owns 32 intermediate positions x all channels;
 //   * + b1, LeakyReLU, zero outside [0,T) (conv2 pads the ACTIVATED intermediate) -> LDS h[c][m] (aliases the window ring);
 //   * conv2 over h, + b2 + residual x, alpha / beta accumulation into the MRF sum through the staged 16-byte epilogue.
 // Same chunk -> tap -> channel-pair accumulation order and the same epilogue arithmetic as conv1d_f32_kernel / conv1d_f32g_kernel:
