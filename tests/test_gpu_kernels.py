@@ -359,6 +359,8 @@ G_CASES = [  # B, Ci, T, Co, k, dil, in_act, res  - every case takes conv1d_f32g
     (1, 48, 132, 100, 1, 1, 0, True),       # k = 1: a new window every ring step; Co not a multiple of 32
     (1, 16, 64, 36, 2, 1, 0, False),        # one chunk, two taps
     (3, 128, 752, 1536, 3, 1, 0, False),    # 96-sample tiles win the tile choice at this shape
+    (1, 32, 752, 1536, 3, 1, 0, True),      # one clip: 64 x 128 tiles (the launch would make 96 workgroups of 128 x 96)
+    (1, 64, 752, 768, 3, 1, 1, True),       # one clip, 768 channels: 64 x 64 tiles
 ]
 
 

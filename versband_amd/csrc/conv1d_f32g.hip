@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
     constexpr int WPW = NWI >= 4 ? NWI / 4 : 1;           // ... per wave (narrow tiles: the waves repeat each other's pieces)
     constexpr int XPW = UPS ? 4 * NP : NP;                // window pieces per wave and chunk (16-B lanes: 4 rows of 64 positions per piece)
     static_assert(NSW == 3 || NSW == 4, "g_wait_tile counts at most two tiles ahead");
-    static_assert(2 * XST * sizeof(float) >= 4 * 32 * CE_PITCH * sizeof(float), "staging patches must fit in the window ring");
+    static_assert((2 * XST + NSW * WT) * sizeof(float) >= 4 * 32 * CE_PITCH * sizeof(float), "staging patches must fit in the rings (contiguous)");
     extern __shared__ __attribute__((aligned(16))) float g_lds[];
     float* lx = g_lds;
     float* lw = g_lds + 2 * XST;
@@ -243,21 +243,37 @@ static void launch_cfg_g(ConvDev& d, int n_count, int B, hipStream_t st) {
     vb_set_max_lds_once(once, (const void*)conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW>, BYTES);
     hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
 }
-// tile choice of the DMA-fed kernel for wide layers: 128 channels x 128 or 96 samples - whichever leaves the busiest CU fewer samples
-// (the 1536-channel VAE layers at 8 clips: 576 workgroups of 128 samples = 3 on the busiest CU, 768 of 96 = 3 as well, 384 against 288)
-static bool g_prefer_96(int n_count, int Co, int B, int phases) {
-    const int64_t w128 = (int64_t)cdiv(n_count, 128) * cdiv(Co, 128) * B * phases, w96 = (int64_t)cdiv(n_count, 96) * cdiv(Co, 128) * B * phases;
-    return cdiv(w96, 256) * 96 < cdiv(w128, 256) * 128;
+// Tile choice for wide layers (Co > 64).  Every configuration walks chunks, taps and channel pairs in the same order - the choice never
+// changes a bit of the result - so it is free to follow the launch's size: the busiest CU's load (workgroups on it x tile area) over a
+// per-tile efficiency (MFMAs between two barriers: 32 / 24 / 16 / 8 per wave).  8 clips: the vocoder's 128 / 256-channel layers take
+// 128 x 128, the 1536 / 768-channel VAE layers 128 x 96 (768 workgroups = one round at three per CU); one or two clips: the VAE layers make
+// 48-96 workgroups of those tiles for 256 CUs and take 64 x 128 or 64 x 64 instead (one clip: fp32 conv class 14.6 -> 12.1 ms per pass).
+static int g_pick_tile(int n_count, int Co, int B, int phases) {
+    struct Cand { int id, co, t; double eff; };
+    static const Cand cands[4] = {{0, 128, 128, 1.00}, {1, 128, 96, 0.95}, {2, 64, 128, 0.85}, {3, 64, 64, 0.70}};
+    int best = 0;
+    double best_cost = 1e30;
+    for (const Cand& c : cands) {
+        const int64_t wgs = (int64_t)cdiv(n_count, c.t) * cdiv(Co, c.co) * B * phases;
+        const double cost = (double)cdiv(wgs, 256) * c.co * c.t / c.eff;
+        if (cost < best_cost * 0.999) { best_cost = cost; best = c.id; }
+    }
+    return best;
 }
 
 // picks the tile and launches; the caller (launch_conv1d) has checked the kernel's conditions
 void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream_t st) {
     if (upsample2) {
-        if (g_prefer_96(n_count, d.Co, B, d.phases)) launch_cfg_g<4, 1, 1, 3, true, 3>(d, n_count, B, st);
+        const int64_t w128 = (int64_t)cdiv(n_count, 128) * cdiv(d.Co, 128) * B, w96 = (int64_t)cdiv(n_count, 96) * cdiv(d.Co, 128) * B;
+        if (cdiv(w96, 256) * 96 < cdiv(w128, 256) * 128) launch_cfg_g<4, 1, 1, 3, true, 3>(d, n_count, B, st);
         else launch_cfg_g<2, 2, 2, 2, true, 3>(d, n_count, B, st);
     } else if (d.Co > 64) {
-        if (g_prefer_96(n_count, d.Co, B, d.phases)) launch_cfg_g<4, 1, 1, 3, false, 3>(d, n_count, B, st);
-        else launch_cfg_g<2, 2, 2, 2, false, 3>(d, n_count, B, st);      // 3-stage ring: 49 KB, three workgroups per CU (31.3 -> 30.4 ms per pass against 4 stages / two)
+        switch (g_pick_tile(n_count, d.Co, B, d.phases)) {
+            case 1: launch_cfg_g<4, 1, 1, 3, false, 3>(d, n_count, B, st); break;
+            case 2: launch_cfg_g<2, 2, 1, 2, false, 4>(d, n_count, B, st); break;
+            case 3: launch_cfg_g<2, 2, 1, 1, false, 3>(d, n_count, B, st); break;
+            default: launch_cfg_g<2, 2, 2, 2, false, 3>(d, n_count, B, st);     // 3-stage ring: 49 KB, three workgroups per CU (31.3 -> 30.4 ms per pass against 4 stages / two)
+        }
     } else if (d.Co > 32) launch_cfg_g<2, 2, 1, 2, false>(d, n_count, B, st);
     else launch_cfg_g<1, 4, 1, 2, false>(d, n_count, B, st);
 }
