@@ -1,6 +1,7 @@
 // DMA-fed exact-fp32 Conv1d / ConvTranspose1d (v_mfma_f32_32x32x2_f32) - its own translation unit because it is built with
 // -mllvm -amdgpu-mfma-vgpr-form (accumulators stay in VGPRs: the asm-pipelined loop below otherwise gets its accumulators copied between
 // VGPRs and AGPRs around every ring step); see versband_amd/build.py.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "conv1d_dev.h"
@@ -179,6 +180,11 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
     }
     int ch = 0, j = 0;                   // tile t = (ch, j)
     int slot = 0, nslot = NSW - 1;
+    float da[TM], dbv[TN];               // held-back operands of a step's last channel pair
+#pragma unroll
+    for (int i = 0; i < TM; ++i) da[i] = 0.f;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) dbv[jn] = 0.f;
     for (int t = 0; t < total; ++t) {
         const int ahead_all = min(total - 1, t + NSW - 2) - t;
         if (j == 0) {
@@ -206,6 +212,17 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
         };
         fload(std::integral_constant<int, 0>{});
         fload(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // the LAST channel pair of the previous step was held back (operands in registers): its MFMAs are queued here, behind the barrier,
+        // the DMA issue and the first two fragment requests of this step - 256 matrix-pipe cycles that cover the first LDS round trip
+        // (same box: 810 -> 798 us on the 128 x 128 tile; at three workgroups per CU most of it was hidden already).
+        // Same accumulation order (they still precede this step's first pair); the first step queues zeros.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], dbv[jn], acc[i][jn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         g_static_for<0, GK / 2>([&](auto kc) {
             constexpr int KK = decltype(kc)::value, S = KK % 3;
             if constexpr (KK + 1 < GK / 2) LDS_WAIT(TM + TN); else LDS_WAIT(0);
@@ -217,17 +234,29 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
             float bv[TN];
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) bv[jn] = fmaxf(bb[S][jn], bb[S][jn] * slope);
+            if constexpr (KK + 1 < GK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][i], bv[jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < TN; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][i], bv[jn], acc[i][jn], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) da[i] = a[S][i];
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) dbv[jn] = bv[jn];
+            }
         });
         if (++j == p.ntaps) { j = 0; ++ch; }
         if (++nj == p.ntaps) { nj = 0; ++nch; }
         if (++slot == NSW) slot = 0;
         if (++nslot == NSW) nslot = 0;
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], dbv[jn], acc[i][jn], 0, 0, 0);       // the last step's held-back pair
     __syncthreads();                     // the window ring is free: it holds the four wave-private staging patches now
     if (p.stage_epi) conv_epilogue_staged<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, lx);
     else conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
