@@ -76,6 +76,12 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+def _class_patterns(cls):
+    """kernel-name patterns of a class id or of a group (tuple) of class ids"""
+    ids = cls if isinstance(cls, (tuple, list)) else (cls,)
+    return tuple(p for c in ids for p in CLASS_KERNELS[c])
+
+
 def pmc_traffic(cls):
     """HBM bytes per launch of a kernel class from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_summary.json:
     separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this same command; counter unit = KB; FETCH_SIZE doubled for gfx950 as
@@ -90,18 +96,18 @@ def pmc_traffic(cls):
         d = json.load(open(path))
         tot, n = 0.0, 0
         for name, v in d.get("FETCH_SIZE", {}).items():
-            if any(k in name for k in CLASS_KERNELS[cls]):
+            if any(k in name for k in _class_patterns(cls)):
                 tot += 2.0 * v["sum_kb"] * 1024.0
                 n += v["launches"]
         for name, v in d.get("WRITE_SIZE", {}).items():
-            if any(k in name for k in CLASS_KERNELS[cls]):
+            if any(k in name for k in _class_patterns(cls)):
                 tot += v["sum_kb"] * 1024.0
         return ((tot / n) if n else None), os.path.relpath(path, ROOT)
     except Exception:
         return None, None
 
 
-def pmc_traffic_live(cls, timeout, vocoder_precision="fp32"):
+def pmc_traffic_live(cls, timeout, vocoder_precision="fp32", launches_per_pass=None):
     """HBM bytes per launch of a kernel class MEASURED IN THIS RUN: two child runs of this same command (one stream, one pass, no
     baseline legs) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes: the two counters do
     not fit the TCC's 4 slots together), counter unit = KB, FETCH_SIZE doubled for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md
@@ -120,6 +126,7 @@ def pmc_traffic_live(cls, timeout, vocoder_precision="fp32"):
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     perk = {}
+    passes = None
     for ctr, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         d = tempfile.mkdtemp(prefix="vb_pmc_")
         cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable, os.path.abspath(__file__),
@@ -130,6 +137,9 @@ def pmc_traffic_live(cls, timeout, vocoder_precision="fp32"):
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not fs:
                 return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {r.stderr[-200:]}", None
+            m = re.search(r"PASSES_RUN=(\d+)", r.stderr)
+            if m:
+                passes = int(m.group(1))
             kb, launches = 0.0, 0
             for row in csv.DictReader(open(fs[0])):
                 if row["Counter_Name"] != ctr:
@@ -139,7 +149,7 @@ def pmc_traffic_live(cls, timeout, vocoder_precision="fp32"):
                 e[ctr] += mult * float(row["Counter_Value"]) * 1024.0
                 if ctr == "FETCH_SIZE":
                     e["launches"] += 1
-                if any(k in row["Kernel_Name"] for k in CLASS_KERNELS[cls]):
+                if any(k in row["Kernel_Name"] for k in _class_patterns(cls)):
                     kb += float(row["Counter_Value"])
                     launches += 1
             tot += mult * kb * 1024.0
@@ -152,8 +162,17 @@ def pmc_traffic_live(cls, timeout, vocoder_precision="fp32"):
               "fetch_mb_per_launch": v["FETCH_SIZE"] / max(v["launches"], 1) / 1e6, "write_mb_per_launch": v["WRITE_SIZE"] / max(v["launches"], 1) / 1e6,
               "total_gb": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) / 1e9}
              for k, v in sorted(perk.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"] + kv[1]["WRITE_SIZE"])) if v["launches"]][:40]
-    return ((tot / n) if n else None), (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
-                                       f"(--streams 1, one pass incl. its warmup passes, {n} launches of the class; FETCH doubled per the gfx950 note)"), table
+    if passes and launches_per_pass:
+        # the class's launch count of the isolated pass (the profiler's own classes: proj_in's GEMM counts as convolution work there, by
+        # kernel NAME it is a GEMM) - bytes per pass of the named kernels / launches per pass of the class
+        per_launch = tot / passes / launches_per_pass
+        how = (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (--streams 1, {passes} passes, "
+               f"{n} launches of the group's kernels = {tot / passes / 1e9:.1f} GB per pass, / {launches_per_pass:.0f} launches per pass; FETCH doubled per the gfx950 note)")
+    else:
+        per_launch = (tot / n) if n else None
+        how = (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
+               f"(--streams 1, one pass incl. its warmup passes, {n} launches of the class; FETCH doubled per the gfx950 note)")
+    return per_launch, how, table
 
 
 class Telemetry:
@@ -533,8 +552,12 @@ def main():
     for si in range(S):
         workers.append(make_worker(sizes[si], rank * B + sum(sizes[:si]), share=workers[0]["eng"] if workers else None))
 
+    passes_run = [0]
+
     def one_pass(w, k, second=False):
         n = w["sec"] if second else w          # the nets and the result slots of this precision
+        if w is workers[0]:
+            passes_run[0] += 1
         if long:
             z = longform.sample_long(w["eng"], w["x0"], w["t5c"], w["t5u"], w["midi"], w["beats"], idx, dts, args.scale,
                                      window=dcfg.max_len, overlap=128, seed=SEED + k, clip_base=w["clip_base"])
@@ -626,6 +649,10 @@ def main():
                          # double the reading of the long conv kernels (60.8 ms against rocprofv3's 30), while a sampled launch between
                          # un-bracketed neighbours agrees with rocprofv3 to 2 %.
     table, table_sec, dominant = [], [], 0
+    GROUPS = {"bf16 MFMA GEMMs of the DiT (projections, routed + band experts)": (0,), "bf16 flash attention (self + T5 cross)": (1,),
+              f"VAE + vocoder convolutions in {'exact fp32 (v_mfma_f32_32x32x2_f32)' if prim == 'fp32' else 'split-bf16 (bf16x3)'}: implicit-GEMM conv1d + "
+              "fused HiFi-GAN ResBlock pairs": (2, 3)}
+    groups, dom_group = [], None
 
     def class_rows(per, cls_meta, passes):
         rows = []
@@ -651,7 +678,22 @@ def main():
         per = {cls: read_prof(cls) for cls in CLS}
         table = class_rows(per, CLS, PROF_PASSES)
         L.check(lib.vb_prof_enable(0), "prof")
+        # "dominant" = the kernel GROUP with the largest GPU time per pass.  The two convolution classes are one group - the VAE / vocoder
+        # convolutions run on two kernel families (implicit-GEMM conv1d, fused ResBlock pairs) the way the GEMM class runs on six - and
+        # with the fp32 vocoder of configs[1] that group IS the largest part of a pass; every class keeps its own row in `classes`.
+        for gname, ids in GROUPS.items():
+            tms = sum(per[c][0] * per[c][3] / per[c][4] for c in ids if per[c][4]) / PROF_PASSES
+            tfl = sum(per[c][1] * per[c][3] / per[c][4] for c in ids if per[c][4]) / PROF_PASSES
+            tby = sum(per[c][2] * per[c][3] / per[c][4] for c in ids if per[c][4]) / PROF_PASSES
+            nl = sum(per[c][3] for c in ids if per[c][4]) / PROF_PASSES
+            if tms > 0:
+                groups.append({"group": gname, "classes": [CLS[c][0] for c in ids], "class_ids": list(ids), "ms_per_pass": tms, "launches_per_pass": nl,
+                               "avg_launch_us": 1e3 * tms / nl, "tflops": tfl / (tms * 1e-3) / 1e12, "mfma_peak_tflops": CLS[ids[0]][2],
+                               "frac_of_mfma_peak": tfl / (tms * 1e-3) / 1e12 / CLS[ids[0]][2], "algorithmic_mb_per_launch": tby / nl / 1e6})
+        dom_group = max(groups, key=lambda g: g["ms_per_pass"]) if groups else None
         dominant = max(per, key=lambda c: per[c][0] * (per[c][3] / per[c][4]) if per[c][4] else 0.0)
+        if dom_group:
+            dominant = max(dom_group["class_ids"], key=lambda c: per[c][0] * (per[c][3] / per[c][4]) if per[c][4] else 0.0)
         if sec:
             # the convolution classes once more with the bf16x3 nets (classes 2 and 3 only: the DiT classes do not change)
             run_worker(w, [-110], True)
@@ -777,16 +819,22 @@ def main():
         conc = (fl / (ms * 1e-3) / 1e12) if (ms > 0 and nt > 0) else 0.0      # flops and time of the timed launches
         iso = next((r for r in table if r["class"] == name), None)
         achieved = iso["tflops"] if iso else conc
+        pmc_cls = dominant
+        if dom_group:
+            # the line's roofline block describes the dominant GROUP (launch-weighted over its classes); `classes` holds every class on its own
+            name, peak, achieved = dom_group["group"], dom_group["mfma_peak_tflops"], dom_group["tflops"]
+            iso = dict(dom_group)
+            pmc_cls = tuple(dom_group["class_ids"])
         # the committed PMC passes were taken on the default command (c2, 8 clips): for any other workload the per-launch figure does not apply
         pmc_applies = args.workload == "c2" and B == 8 and args.experts == 4 and abs(clip_seconds - 20.0) < 1e-9
         traffic, traffic_file, traffic_how, traffic_table = None, None, None, None
         if pmc_applies and world == 1 and not args.no_pmc:
             log("PMC traffic passes (rocprofv3 child runs)")
-            traffic, traffic_how, traffic_table = pmc_traffic_live(dominant, args.pmc_timeout, prim)
+            traffic, traffic_how, traffic_table = pmc_traffic_live(pmc_cls, args.pmc_timeout, prim, iso["launches_per_pass"] if iso else None)
             log(f"traffic: {traffic} ({traffic_how})")
         if traffic is None and pmc_applies:
             live_why = traffic_how
-            traffic, traffic_file = pmc_traffic(dominant)
+            traffic, traffic_file = pmc_traffic(pmc_cls)
             traffic_how = (f"file: {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH doubled per the gfx950 note"
                            + (f"; live measurement unavailable: {live_why}" if live_why else "") + ")") if traffic else live_why
         total_mel_s = world * B * clip_seconds * args.steps
@@ -828,9 +876,11 @@ def main():
             "parity_check": parity,
             "device": {"name": torch.cuda.get_device_name(device), "clocks_during_timed_region": tele.summary(device)},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "how": ("dominant class = largest GPU time per pass; achieved = algorithmic flops of its event-timed launches / their "
-                                 "summed durations, measured in this run with the class ALONE on the GPU (one stream, whole batch, every 7th "
-                                 "launch bracketed by HIP events on the launch stream)") if iso else "timed-region launches (no isolated pass)",
+                         "how": ("dominant group = largest GPU time per pass (the two convolution classes count as one group, like the six GEMM kernels "
+                                 "count as one class); achieved = algorithmic flops of its launches / their durations, from the event-timed launches "
+                                 "of each of its classes scaled to the class's launch count, measured in this run with every class ALONE on the GPU "
+                                 "(one stream, whole batch, every 7th launch bracketed by HIP events on the launch stream); `classes` and `groups` "
+                                 "list every class / group the same way") if iso else "timed-region launches (no isolated pass)",
                          "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
                          "traffic": traffic, "traffic_per_kernel": traffic_table,
                          "traffic_source": traffic_how if pmc_applies else
@@ -843,7 +893,7 @@ def main():
                                                    "duration includes that overlap (not a kernel-quality figure)"} if args.profile_timed else
                                           "not event-bracketed: the timed region replays the sampler loop as a hipGraph (run with --profile-timed "
                                           "for eager launches + in-region events)"),
-                         "classes": table},
+                         "classes": table, "groups": [{k: v for k, v in g.items() if k != "class_ids"} for g in groups]},
         }
         if sec:
             out["split"] = {
@@ -858,6 +908,8 @@ def main():
         print(json.dumps(out))
         if (parity is not None and parity.get("ok") is False) or (parity_sec is not None and parity_sec.get("ok") is False):
             log("PARITY CHECK FAILED")
+    if rank == 0:
+        log(f"PASSES_RUN={passes_run[0]}")      # (read back by the PMC child-run parser: counter sums -> bytes per pass)
     if args.save_out:
         import numpy as np
         os.makedirs(args.save_out, exist_ok=True)
