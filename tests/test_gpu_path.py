@@ -637,6 +637,15 @@ def test_fullsize_reference_digests(ctx, engines):
     wav = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams()).run(mel)
     torch.cuda.synchronize()
     check_digest(wav, g, "voc_wav_", 1e-3)
+    # the exact-fp32 VAE / vocoder (round 4: what bench.py's `value` runs) at the same geometry, against the same digests of the reference:
+    # DMA-fed f32-MFMA kernels incl. the small tiles one clip selects, nearest x2 under DMA, per-clip weights (VAE attention), fused fp32 pairs
+    mel32 = build_vae_decoder(ctx, synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1), precision="fp32").run(z)
+    check_digest(mel32, g, "vae_mel_", 2e-6)       # measured: sampled error 1.5e-6 of max-abs, L2 6.7e-8 (split: 1.0e-5 / 4.0e-7)
+    mom32 = build_vae_encoder(ctx, synth.make_state_dict(synth.vae_encoder_shapes(vcfg), SEED + 3), precision="fp32").run(mel32)
+    check_digest(mom32, g, "vae_moments_", 2e-5)
+    wav32 = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision="fp32").run(mel32)
+    torch.cuda.synchronize()
+    check_digest(wav32, g, "voc_wav_", 2e-6)       # measured: 1.2e-6 / 1.7e-8 (split: 7.5e-6 / 1.4e-6)
 
 
 def test_t5_encoder_vs_transformers_golden_and_oracle(ctx):
