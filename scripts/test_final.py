@@ -58,6 +58,8 @@ def parse_args():
     p.add_argument("--synthetic", type=int, default=0, help="run N synthetic items with random-init checkpoints")
     p.add_argument("--synthetic_frames", type=int, default=1500)
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "split"])
+    p.add_argument("--vocoder_precision", type=str, default="fp32", choices=["fp32", "split"],
+                   help="VAE + vocoder arithmetic: fp32 = the reference's (f32 MFMA kernels), split = bf16x3 (<= 3e-5 of it, ~1.3x faster end to end)")
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--dummy_text", action="store_true",
                    help="text captions get seeded stand-in embeddings instead of FLAN-T5 (no T5 weights / tokenizer needed); without "
@@ -85,6 +87,7 @@ class SyntheticDataset:
 def initialize_model(args, device, rank=0):
     config = load_config(args.config)
     config.model.params["precision"] = args.precision
+    config.model.params["vocoder_precision"] = args.vocoder_precision
     if args.dummy_text:
         config.model.params["cond_stage_config"]["params"]["dummy_text"] = True
     model = instantiate_from_config(config.model)
@@ -114,7 +117,7 @@ def make_vocoder(args, device, tmp_dir, rank=0):
     voc = None
     if rank == 0:
         if args.vocoder_ckpt:
-            voc = HifiGAN(vocoder_ckpt=args.vocoder_ckpt, device=device)
+            voc = HifiGAN(vocoder_ckpt=args.vocoder_ckpt, device=device, precision=args.vocoder_precision)
         else:
             import yaml
             hcfg = synth.HifiGanConfig()
@@ -122,13 +125,13 @@ def make_vocoder(args, device, tmp_dir, rank=0):
             yaml.safe_dump(hcfg.as_hparams(), open(os.path.join(tmp_dir, "config.yaml"), "w"))
             torch.save({"state_dict": {"model_gen": synth.make_state_dict(synth.hifigan_shapes(hcfg), args.seed + 2)}},
                        os.path.join(tmp_dir, "model_ckpt_steps_0.ckpt"))
-            voc = HifiGAN(vocoder_ckpt=tmp_dir, device=device)
+            voc = HifiGAN(vocoder_ckpt=tmp_dir, device=device, precision=args.vocoder_precision)
     if not multi:
         return voc
     box = [dict(voc.config) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     state, _ = vdist.broadcast_state(voc.state if rank == 0 else None, 0, device)
-    return voc if rank == 0 else HifiGAN.from_state(box[0], state, device)
+    return voc if rank == 0 else HifiGAN.from_state(box[0], state, device, precision=args.vocoder_precision)
 
 
 def _mono(a):

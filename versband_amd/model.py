@@ -121,6 +121,7 @@ class AutoencoderKL:
     enc_state: Dict[str, Tensor] = {}
     enc_net = None
     _device = None
+    _precision = "fp32"          # VAE arithmetic: the reference's fp32 (default) or "split" = bf16x3 (set by CFM(vocoder_precision=...))
 
     def encode(self, x):
         """:49-53  mel [B,80,T_mel] -> DiagonalGaussianDistribution over z [B,embed_dim,T_mel/2] (HIP encoder net)."""
@@ -128,7 +129,7 @@ class AutoencoderKL:
         if self.enc_net is None:
             if not self.enc_state:
                 raise RuntimeError("AutoencoderKL.encode: no encoder.* / quant_conv.* weights loaded")
-            self.enc_net = build_vae_encoder(Context(self._device or "cuda:0"), self.enc_state)
+            self.enc_net = build_vae_encoder(Context(self._device or "cuda:0"), self.enc_state, precision=self._precision)
         return DiagonalGaussianDistribution(self.enc_net.run(x))
 
 
@@ -251,7 +252,9 @@ class FrozenTextVocalEmbedder:
 class CFM:
     def __init__(self, unet_config=None, first_stage_config=None, cond_stage_config=None, timesteps=1000, mel_dim=80,
                  mel_length=848, channels=0, conditioning_key=None, scale_by_std=False, scale_factor=1.0, precision="bf16",
-                 **ignored):
+                 vocoder_precision="fp32", **ignored):
+        # precision: the DiT ("bf16" production / "split" = bf16x3 parity mode).  vocoder_precision: the first-stage VAE ("fp32" = the
+        # reference's arithmetic on the f32 MFMA, the default since round 4; "split" = bf16x3, <= 3e-5 of it and 1.3x faster end to end)
         self.num_timesteps = timesteps
         self.mel_dim, self.mel_length, self.channels = mel_dim, mel_length, channels
         self.sigma_min = 1e-4
@@ -261,6 +264,9 @@ class CFM:
         self.cond_stage_forward = None
         self.scale_factor = torch.tensor(float(scale_factor))
         self.precision = precision
+        assert vocoder_precision in ("fp32", "split"), vocoder_precision
+        self.vocoder_precision = vocoder_precision
+        self.first_stage_model._precision = vocoder_precision
         self.device = torch.device("cpu")
         self._dit_state: Dict[str, Tensor] = {}
         self._ctx = None
@@ -325,7 +331,7 @@ class CFM:
         if fs.net is None:
             if not fs.state:
                 raise RuntimeError("CFM: no first_stage_model weights loaded")
-            fs.net = build_vae_decoder(ctx, fs.state, scale_factor=float(self.scale_factor))
+            fs.net = build_vae_decoder(ctx, fs.state, scale_factor=float(self.scale_factor), precision=self.vocoder_precision)
         return fs.net
 
     # -- reference API -----------------------------------------------------
@@ -497,7 +503,11 @@ def load_ckpt_state(ckpt_base_dir: str, model_name: str = "model_gen") -> Dict[s
 
 
 class HifiGAN:
-    def __init__(self, vocoder_ckpt, device=None):
+    def __init__(self, vocoder_ckpt, device=None, precision="fp32"):
+        """vocoder/hifigan/hifigan.py:7-18.  precision: "fp32" = the reference's arithmetic (f32 MFMA; default since round 4),
+        "split" = bf16x3 (<= 3e-5 of it, faster)"""
+        assert precision in ("fp32", "split"), precision
+        self.precision = precision
         base_dir = vocoder_ckpt
         self.config = set_hparams(f"{base_dir}/config.yaml")
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -506,10 +516,11 @@ class HifiGAN:
         self._ctx = None
 
     @classmethod
-    def from_state(cls, config: dict, state: dict, device=None) -> "HifiGAN":
+    def from_state(cls, config: dict, state: dict, device=None, precision="fp32") -> "HifiGAN":
         """the generator from an already loaded config + `model_gen` state dict (multi-GPU runs: rank 0 reads <vocoder_ckpt> and the
         weights reach the other ranks through versband_amd.dist.broadcast_state instead of N disk reads)"""
         self = cls.__new__(cls)
+        self.precision = precision
         self.config = dict(config)
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.state = state
@@ -521,7 +532,7 @@ class HifiGAN:
         from .engine import Context, build_hifigan
         if self._net is None:
             self._ctx = Context(self.device)
-            self._net = build_hifigan(self._ctx, self.state, self.config)
+            self._net = build_hifigan(self._ctx, self.state, self.config, precision=self.precision)
         return self._net
 
     def spec2wav(self, mel, **kwargs):
@@ -549,8 +560,10 @@ class VocoderBigVGAN:
     """vocoder/bigvgan/models.py:393-414: <ckpt_vocoder>/best_netG.pt ['generator'] + <ckpt_vocoder>/args.yml -> BigVGAN generator
     on the HIP library (engine.build_bigvgan)."""
 
-    def __init__(self, ckpt_vocoder, device="cuda"):
+    def __init__(self, ckpt_vocoder, device="cuda", precision="fp32"):
         import yaml
+        assert precision in ("fp32", "split"), precision
+        self.precision = precision
         sd = torch.load(os.path.join(ckpt_vocoder, "best_netG.pt"), map_location="cpu")
         self.state = {k: v for k, v in sd["generator"].items() if not k.endswith("filter")}     # the filters are recomputed
         with open(os.path.join(ckpt_vocoder, "args.yml")) as f:
@@ -561,7 +574,7 @@ class VocoderBigVGAN:
     def net(self):
         from .engine import Context, build_bigvgan
         if self._net is None:
-            self._net = build_bigvgan(Context(self.device), self.state, self.h)
+            self._net = build_bigvgan(Context(self.device), self.state, self.h, precision=self.precision)
         return self._net
 
     def vocode(self, spec):
