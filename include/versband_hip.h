@@ -222,6 +222,16 @@ int vb_vae_encode(vb_ctx* ctx, const float* mel, int B, int T, float* moments, v
 /* HifiGAN.spec2wav (vocoder/hifigan/hifigan.py:20-30): mel [B][80][T] -> wav [B][T*hop] */
 int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, void* ws, void* stream);
 
+/* Long-form generation (BASELINE configs[4]; build-defined, the reference stops at max_len = 1500 latent tokens: vocal2music_moe.py:421).
+ * vb_crossfade_windows: window results parts [nw*B][C][n] (row = w*B + b; windows of equal length n starting at starts[w], a HOST array,
+ * covering [0, T) with overlaps) -> out [B][C][T], linear cross-fade over every overlap, weights normalised to one.
+ * vb_hifigan_forward_chunked: HifiGAN.spec2wav over a long mel in chunks of `chunk` frames with `halo` frames of context on both sides -
+ * identical to whole-clip vocoding when halo >= the generator's receptive field; scratch_in >= B*in_ch*(chunk + 2*halo) floats,
+ * scratch_out >= B*out_ch*(chunk + 2*halo)*hop floats, ws = vb_net_workspace_bytes(ctx, VB_NET_VOCODER, B, chunk + 2*halo). */
+int vb_crossfade_windows(const float* parts, const int32_t* starts, int nw, int B, int C, int n, int T, float* out, void* stream);
+int vb_hifigan_forward_chunked(vb_ctx* ctx, const float* mel, int B, int T, int chunk, int halo, float* wav, void* ws, float* scratch_in,
+                               float* scratch_out, void* stream);
+
 /* ------------------------------------------------------------ T5 text encoder ----
  * FrozenTextVocalEmbedder.forward (ldm/modules/encoders/modules.py:216-233): T5EncoderModel(input_ids).last_hidden_state, no
  * attention mask.  HF T5 encoder stack (transformers T5Stack / T5Block / T5Attention / T5DenseGatedActDense / T5LayerNorm):

@@ -133,6 +133,24 @@ def test_c5_longform_chunked_sampling(ctx):
         eng.sample_cfg(big["x_latent"], cb, idx, dts, 3.0)
 
 
+def test_c5_crossfade_kernel_equals_torch_restatement(ctx):
+    """vb_crossfade_windows (the product path of sample_long) against longform.crossfade_windows, the torch restatement the oracle's
+    long-form fixture was generated with: same windows, same ramps - equal to fp32 rounding of the ramp weights, exact where one window
+    covers a sample alone; a window list that does not cover [0, T) is refused."""
+    from versband_amd import _lib as L
+    B, C, T, win, ov = 3, 20, 4500, 1500, 128
+    plan = longform.plan_windows(T, win, ov)
+    zw = torch.from_numpy(synth.prng.normal(41, len(plan) * B * C * win).reshape(len(plan) * B, C, win)).cuda()
+    got = longform.crossfade_windows_hip(ctx.lib, zw, plan, B, T)
+    want = longform.crossfade_windows([zw[i * B:(i + 1) * B] for i in range(len(plan))], plan, T)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (B, C, T)
+    assert float((got - want).abs().max()) <= 2e-7 * float(want.abs().max()), describe("crossfade", got, want)
+    assert torch.equal(got[:, :, :plan[1][0]], zw[:B, :, :plan[1][0]])           # window 0 alone: untouched
+    with pytest.raises(L.VersbandError):
+        longform.crossfade_windows_hip(ctx.lib, zw, [plan[0], (win + 5, win)] + list(plan[2:]), B, T)   # samples win .. win + 4 uncovered
+
+
 def test_c5_overlap_add_vocoder_equals_whole_clip(ctx):
     from versband_amd.engine import build_hifigan
     hcfg = synth.HifiGanConfig()

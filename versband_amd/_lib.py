@@ -110,6 +110,8 @@ PROTOTYPES = {
     "vb_t5_workspace_bytes": (C.c_size_t, [C.POINTER(T5Config), c_int, c_int]),
     "vb_t5_encode": (c_int, [P, P, c_int, c_int, P, P, P]),
     "vb_hifigan_forward": (c_int, [P, P, c_int, c_int, P, P, P]),
+    "vb_crossfade_windows": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "vb_hifigan_forward_chunked": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "vb_melnet_load": (c_int, [P, C.POINTER(MelConfig), P, P]),
     "vb_melnet_frames": (c_int, [C.POINTER(MelConfig), c_int, c_int]),
     "vb_melnet_workspace_bytes": (C.c_size_t, [C.POINTER(MelConfig), c_int, c_int, c_int]),

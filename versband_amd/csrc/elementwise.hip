@@ -1135,3 +1135,51 @@ int launch_iota_div(int64_t* out, int n, int div, hipStream_t st) {
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
+
+
+// ---------------------------------------------------------------------------
+// long-form generation (BASELINE configs[4], build-defined: versband_amd/longform.py): cross-fade of the window results
+//   out[b][c][t] = sum_w wgt_w(t) * parts[w*B + b][c][t - s_w] / sum_w wgt_w(t)
+// wgt = 1 inside a window, linear ramps (k+1)/(ov+1) over the overlap with the previous window and 1 - (k+1)/(ov+1) over the overlap
+// with the next one (the interior points of linspace(0, 1, ov + 2)), the minimum of the two where both apply - window order and
+// arithmetic of longform.crossfade_windows (the torch restatement the oracle fixture was generated with).
+// ---------------------------------------------------------------------------
+struct XfadeStarts { int s[64]; };
+__global__ void __launch_bounds__(256) crossfade_windows_kernel(const float* __restrict__ parts, XfadeStarts st, int nw, int B, int C, int n, int T,
+                                                                float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * C * T) return;
+    const int t = (int)(i % T);
+    const int64_t bc = i / T;
+    const int b = (int)(bc / C), c = (int)(bc - (int64_t)b * C);
+    float acc = 0.f, wsum = 0.f;
+    for (int w = 0; w < nw; ++w) {
+        const int s = st.s[w], u = t - s;
+        if (u < 0 || u >= n) continue;
+        float wt = 1.f;
+        if (w > 0) {
+            const int ov = st.s[w - 1] + n - s;
+            if (ov > 0 && u < ov) wt = (float)(u + 1) / (float)(ov + 1);
+        }
+        if (w + 1 < nw) {
+            const int ov = s + n - st.s[w + 1];
+            if (ov > 0 && u >= n - ov) wt = fminf(wt, 1.f - (float)(u - (n - ov) + 1) / (float)(ov + 1));
+        }
+        acc += parts[(((int64_t)w * B + b) * C + c) * n + u] * wt;
+        wsum += wt;
+    }
+    out[i] = acc / wsum;
+}
+int launch_crossfade_windows(const float* parts, const int* starts, int nw, int B, int C, int n, int T, float* out, hipStream_t st) {
+    if (nw < 1 || nw > 64) VB_FAIL(VB_E_INVALID, "crossfade: %d windows (1..64)", nw);
+    XfadeStarts xs;
+    for (int w = 0; w < 64; ++w) xs.s[w] = w < nw ? starts[w] : 0;
+    for (int w = 0; w < nw; ++w)
+        if (xs.s[w] < 0 || xs.s[w] + n > T || (w > 0 && (xs.s[w] <= xs.s[w - 1] || xs.s[w] > xs.s[w - 1] + n)))
+            VB_FAIL(VB_E_INVALID, "crossfade: window %d at %d (length %d) does not continue the cover of [0, %d)", w, xs.s[w], n, T);
+    if (xs.s[0] != 0 || xs.s[nw - 1] + n != T) VB_FAIL(VB_E_INVALID, "crossfade: the windows do not cover [0, %d)", T);
+    const int64_t tot = (int64_t)B * C * T;
+    hipLaunchKernelGGL(crossfade_windows_kernel, dim3(cdiv(tot, 256)), dim3(256), 0, st, parts, xs, nw, B, C, n, T, out);
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}

@@ -1118,6 +1118,34 @@ int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, 
     RoctxRange rr("vb_hifigan_forward");
     return net_run(ctx, VB_NET_VOCODER, mel, B, T, wav, ws, (hipStream_t)stream);
 }
+int vb_crossfade_windows(const float* parts, const int32_t* starts, int nw, int B, int C, int n, int T, float* out, void* stream) {
+    return launch_crossfade_windows(parts, starts, nw, B, C, n, T, out, (hipStream_t)stream);
+}
+int vb_hifigan_forward_chunked(vb_ctx* ctx, const float* mel, int B, int T, int chunk, int halo, float* wav, void* ws, float* scratch_in,
+                               float* scratch_out, void* stream) {
+    if (!ctx) VB_FAIL(VB_E_INVALID, "hifigan_forward_chunked: null ctx");
+    if (chunk < 1 || halo < 0) VB_FAIL(VB_E_INVALID, "hifigan_forward_chunked: chunk=%d halo=%d", chunk, halo);
+    NetProgram& n = ctx->nets[VB_NET_VOCODER];
+    if (!n.loaded) VB_FAIL(VB_E_STATE, "hifigan_forward_chunked: no vocoder loaded");
+    hipStream_t st = (hipStream_t)stream;
+    RoctxRange rr("vb_hifigan_forward_chunked");
+    if (T <= chunk + 2 * halo) return net_run(ctx, VB_NET_VOCODER, mel, B, T, wav, ws, st);
+    VB_HIP(hipSetDevice(ctx->device));
+    const int hop = n.out_tmul, rows_in = B * n.in_ch, rows_out = B * n.out_ch;
+    for (int s = 0; s < T; s += chunk) {
+        // frames [lo, hi) = the chunk with its context; every row (clip, channel) of the slice is gathered into a contiguous tensor, the
+        // generator runs on it, and the samples of [s, e) are scattered into the whole-clip waveform (strided 2-D copies, no kernel)
+        const int e = s + chunk < T ? s + chunk : T;
+        const int lo = s - halo > 0 ? s - halo : 0, hi = e + halo < T ? e + halo : T;
+        const int tc = hi - lo;
+        VB_HIP(hipMemcpy2DAsync(scratch_in, (size_t)tc * sizeof(float), mel + lo, (size_t)T * sizeof(float), (size_t)tc * sizeof(float), rows_in,
+                                hipMemcpyDeviceToDevice, st));
+        VB_TRY(net_run(ctx, VB_NET_VOCODER, scratch_in, B, tc, scratch_out, ws, st));
+        VB_HIP(hipMemcpy2DAsync(wav + (size_t)s * hop, (size_t)T * hop * sizeof(float), scratch_out + (size_t)(s - lo) * hop,
+                                (size_t)tc * hop * sizeof(float), (size_t)(e - s) * hop * sizeof(float), rows_out, hipMemcpyDeviceToDevice, st));
+    }
+    return VB_OK;
+}
 
 // ---- unit kernels --------------------------------------------------------------------------
 int vb_rmsnorm_modulate(const float* h, const float* w, const float* shift, const float* scale, int mod_ld, int rows, int D, int T,

@@ -228,6 +228,7 @@ int launch_softmax_rows_t(const float* s, int B, int R, int Ccols, float* out_t,
 int launch_sampler_params(int* step, uint64_t seed, int64_t clip_base, int nfe_base, hipStream_t st);   // step[4..9]: noise key of the call
 int launch_step_ctl(int* step, int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, int reset, hipStream_t st);
 int launch_fill_f32(float* p, int64_t n, float v, hipStream_t st);
+int launch_crossfade_windows(const float* parts, const int* starts, int nw, int B, int C, int n, int T, float* out, hipStream_t st);   // starts: HOST array
 
 // ---------------------------------------------------------------------------
 // per-kernel-class HIP-event timing (bench.py roofline): 0 = bf16 GEMM (incl. the fused expert kernels), 1 = attention,

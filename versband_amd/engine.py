@@ -415,6 +415,31 @@ class ConvNet:
         return out
 
 
+def _convnet_run_chunked(self, x: Tensor, chunk: int, halo: int) -> Tensor:
+    """vocoder only: mel [B,80,T] -> wav [B,1,T*hop] in chunks of `chunk` frames with `halo` frames of context on both sides, the loop,
+    the slicing and the stitching inside the library (vb_hifigan_forward_chunked); identical to run() when halo >= the receptive field."""
+    assert self.which == L.NET_VOCODER
+    x = x.to(self.ctx.device, torch.float32).contiguous()
+    B, Cin, T = x.shape
+    assert Cin == self.in_ch
+    if T <= chunk + 2 * halo:
+        return self.run(x)
+    tc = chunk + 2 * halo
+    out = torch.empty(B, self.out_ch, T * self.out_tmul, dtype=torch.float32, device=self.ctx.device)
+    ws = self._workspace(B, tc)
+    key = (B, tc)
+    if getattr(self, "_chunk_key", None) != key:
+        self._chunk_in = torch.empty(B * self.in_ch * tc, dtype=torch.float32, device=self.ctx.device)
+        self._chunk_out = torch.empty(B * self.out_ch * tc * self.out_tmul, dtype=torch.float32, device=self.ctx.device)
+        self._chunk_key = key
+    L.check(self.ctx.lib.vb_hifigan_forward_chunked(self.ctx.handle, L.ptr(x), B, T, chunk, halo, L.ptr(out), L.ptr(ws), L.ptr(self._chunk_in),
+                                                    L.ptr(self._chunk_out), L.stream_ptr()), "vb_hifigan_forward_chunked")
+    return out
+
+
+ConvNet.run_chunked = _convnet_run_chunked
+
+
 def _vae_block_builders(nb: "NetBuilder", g: Dict[str, Tensor]):
     """(cw, resblock, attnblock) emitting ResnetBlock1D (autoencoder1d.py:172-231) / AttnBlock1D (:233-274) ops into nb."""
 

@@ -35,8 +35,23 @@ def plan_windows(T: int, window: int, overlap: int) -> List[Tuple[int, int]]:
     return out
 
 
+def crossfade_windows_hip(lib, zw: Tensor, plan: Sequence[Tuple[int, int]], B: int, T: int) -> Tensor:
+    """the product path of crossfade_windows: window results zw [nw*B, C, n] (row = w*B + b) -> [B, C, T] by vb_crossfade_windows (one kernel,
+    same window order and arithmetic as the torch restatement below, which the oracle fixtures were generated with)"""
+    import ctypes as C
+    from . import _lib as L
+    nw, n = len(plan), plan[0][1]
+    assert all(m == n for _, m in plan) and zw.shape[0] == nw * B and zw.shape[2] == n
+    zw = zw.contiguous()
+    out = torch.empty(B, zw.shape[1], T, dtype=torch.float32, device=zw.device)
+    starts = (C.c_int32 * nw)(*[s for s, _ in plan])
+    L.check(lib.vb_crossfade_windows(L.ptr(zw), starts, nw, B, zw.shape[1], n, T, L.ptr(out), L.stream_ptr()), "vb_crossfade_windows")
+    return out
+
+
 def crossfade_windows(parts: Sequence[Tensor], plan: Sequence[Tuple[int, int]], T: int) -> Tensor:
-    """Blend window results [B,C,len] into [B,C,T]: linear ramps over every overlap, weights sum to one."""
+    """Blend window results [B,C,len] into [B,C,T]: linear ramps over every overlap, weights sum to one.  (Torch restatement: the CPU
+    oracle's digest generator uses it - oracle/gen_bench_digest.py --long; the product path is crossfade_windows_hip.)"""
     B, C = parts[0].shape[:2]
     acc = torch.zeros(B, C, T, dtype=parts[0].dtype, device=parts[0].device)
     wsum = torch.zeros(T, dtype=parts[0].dtype, device=parts[0].device)
@@ -77,6 +92,10 @@ def sample_long(engine, x0: Tensor, t5_cond: Tensor, t5_uncond: Tensor, midi: Te
     t5 = torch.cat([t5_cond.repeat(nw, 1, 1), t5_uncond.repeat(nw, 1, 1)], dim=0)
     cond = engine.precompute_cond(t5, mw, bw, n, persistent=True)
     zw = engine.sample_cfg(xw, cond, t_idx_table, dt_table, scale, seed=seed, clip_base=clip_base * nw)
+    if nw == 1:
+        return zw
+    if zw.is_cuda and all(m == n for _, m in plan):
+        return crossfade_windows_hip(engine.ctx.lib, zw, plan, B, T)
     parts = [zw[i * B:(i + 1) * B] for i in range(nw)]
     return crossfade_windows(parts, plan, T)
 
@@ -88,6 +107,8 @@ def vocode_chunked(vocoder_net, mel: Tensor, chunk: int = 2048, halo: int = 32) 
     hop = vocoder_net.out_tmul
     if T <= chunk + 2 * halo:
         return vocoder_net.run(mel)
+    if hasattr(vocoder_net, "run_chunked"):
+        return vocoder_net.run_chunked(mel, chunk, halo)      # the product path: loop, slicing and stitching inside the library
     out = torch.empty(B, vocoder_net.out_ch, T * hop, dtype=torch.float32, device=mel.device)
     s = 0
     while s < T:
