@@ -91,3 +91,33 @@ def test_every_product_knob_is_documented_and_flipped_by_a_test():
     for k in product:
         assert k in doc, f"{k} is read by the product library but documented nowhere"
         assert k in used, f"{k} is read by the product library but no test or tool sets it"
+
+
+def test_no_kernel_of_the_product_library_uses_scratch(tmp_path):
+    """Round-3 verdict, weak item 9: instances that spill (576-640 B of scratch at 254-256 VGPRs) shipped in the product library.
+    Every kernel of the built libversband_hip.so must run out of registers alone: private_segment_fixed_size = 0 and no spilled VGPR
+    in the code objects' metadata (read from the file, nothing is run; SGPRs parked in VGPR lanes never touch memory and are allowed)."""
+    import shutil
+    import subprocess
+    import pytest
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.isfile(os.path.join(llvm, "llvm-objdump")) and os.path.isfile(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("ROCm LLVM tools not installed")
+    if not os.path.isfile(L.LIB_PATH):
+        pytest.skip("library not built")
+    so = shutil.copy(L.LIB_PATH, str(tmp_path))
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", so], cwd=str(tmp_path), check=True, capture_output=True)
+    objs = [f for f in os.listdir(str(tmp_path)) if "hipv4-amdgcn" in f]
+    assert objs, "no device code object found in the library"
+    kernels, bad = 0, []
+    for f in objs:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(str(tmp_path), f)], check=True, capture_output=True,
+                               text=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vals = {k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1)) for k in ("private_segment_fixed_size", "vgpr_spill_count")}
+            kernels += 1
+            if any(vals.values()):
+                bad.append((name.group(1) if name else "?", vals))
+    assert kernels > 100, f"only {kernels} kernels found - metadata layout changed?"
+    assert not bad, f"kernels with scratch / spills: {bad}"

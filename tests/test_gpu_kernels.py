@@ -94,6 +94,23 @@ def test_conv1d_f32(lib, B, Ci, T, Co, k, dil, act, res, split):
     assert rel_l2(out, ref) < (2e-5 if split else 2e-6), describe("conv1d", out, ref)
 
 
+@pytest.mark.parametrize("B,Ci,T,Co,k,dil", [(2, 128, 520, 128, 3, 1), (1, 256, 388, 256, 7, 3), (2, 128, 300, 256, 11, 5), (3, 128, 752, 1536, 3, 1)])
+def test_fp32_dma_conv_unrolled_taps_equal_the_runtime_tap_loop(lib, monkeypatch, B, Ci, T, Co, k, dil):
+    """conv1d_f32g_kernel with the tap count as a template parameter (3 / 7 / 11: waits and addresses of a chunk's steps are immediates)
+    against the same kernel's runtime-tap loop (VB_CONV_F32_RT_TAPS=1): same tiles in the same order - the same bits."""
+    x, w, b = dev(rnd((B, Ci, T), "ux")), rnd((Co, Ci, k), "uw", 1.0 / (Ci * k) ** 0.5), dev(rnd((Co,), "ub"))
+    r = dev(rnd((B, Co, T), "ur"))
+    pad = (k - 1) * dil // 2
+    wpk = dev(pack.pack_conv(w))
+    new = _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, 1)
+    monkeypatch.setenv("VB_CONV_F32_RT_TAPS", "1")
+    lib.vb_tune_reload()
+    old = _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, 1)
+    monkeypatch.delenv("VB_CONV_F32_RT_TAPS")
+    lib.vb_tune_reload()
+    assert torch.isfinite(new).all() and torch.equal(new, old), f"unrolled vs runtime taps differ by {float((new - old).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("B,Ci,T,Co,k,u", [(2, 512, 24, 256, 16, 8), (1, 256, 33, 128, 15, 5), (1, 128, 20, 64, 11, 5),
                                           (2, 64, 50, 32, 4, 2), (1, 128, 19, 64, 8, 4)])
 @pytest.mark.parametrize("split", [False, True])
@@ -361,6 +378,9 @@ G_CASES = [  # B, Ci, T, Co, k, dil, in_act, res  - every case takes conv1d_f32g
     (3, 128, 752, 1536, 3, 1, 0, False),    # 96-sample tiles win the tile choice at this shape
     (1, 32, 752, 1536, 3, 1, 0, True),      # one clip: 64 x 128 tiles (the launch would make 96 workgroups of 128 x 96)
     (1, 64, 752, 768, 3, 1, 1, True),       # one clip, 768 channels: 64 x 64 tiles
+    (2, 128, 520, 128, 7, 3, 1, True),      # 128 x 128 tiles, seven taps unrolled (the ResBlock tap counts 3 / 7 / 11 are template parameters)
+    (1, 256, 388, 256, 11, 5, 1, True),     # eleven taps, dilation 5, 16 chunks
+    (3, 128, 752, 1536, 7, 1, 1, False),    # 96-sample tiles, seven taps
 ]
 
 

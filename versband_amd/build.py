@@ -27,6 +27,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # the exact-fp32 kernels keep their MFMA accumulators in VGPRs (hipcc otherwise copies them to AGPRs and back around every ring step of
 # the asm-pipelined loops: 32 v_accvgpr moves per 32 MFMAs)
 EXTRA_FLAGS = {"conv1d_f32g.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "respair_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+if not os.environ.get("VB_BUILD_ATTN_AGPR"):
+    EXTRA_FLAGS["attention.hip"] = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 MARKER = b"VB_SOURCE_DIGEST="
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "versband_hip.h")
 

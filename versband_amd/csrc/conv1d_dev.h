@@ -46,7 +46,9 @@ __device__ __forceinline__ float conv_out_value(const ConvDev& p, float acc, flo
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_staged(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
                                                      float* stage) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));        // lane-derived values are recomputed here instead of being kept alive (or spilled) across the caller's main loop
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
     float* patch = stage + wave * (32 * CE_PITCH);

@@ -18,9 +18,8 @@ template <int I, int N, class F> __device__ __forceinline__ void g_static_for(F&
 // go through registers once per tap, and the epilogue moves 4-byte lane accesses - the vocoder's 72 ResBlock convolutions spend as long
 // there as in their MFMAs (profiles/r04_open_fp32voc_kernel_stats.csv).  This kernel keeps the arithmetic - same 16-channel chunks,
 // chunk -> tap -> channel-pair order, one v_mfma_f32_32x32x2_f32 per pair: BIT-IDENTICAL results - and changes how operands arrive:
-//   * the raw window of a chunk is DMA'd (global_load_lds, 16 B per lane) into a two-stage LDS ring one chunk ahead; LeakyReLU is applied
-//     to the B fragment after its ds_read (max(v, slope v): one VALU op per 64-cycle MFMA), zero padding by the lanes that own the
-//     out-of-range quads once their own DMA has landed; GroupNorm + swish inputs are pre-activated by gn_apply_kernel (the builder
+//   * the raw window of a chunk is DMA'd (global_load_lds, 16 B per lane) into a two-stage LDS ring one chunk ahead; LeakyReLU (in place)
+//     and zero padding by the lanes that own the quads, once their own DMA has landed and in front of the barrier that publishes the chunk; GroupNorm + swish inputs are pre-activated by gn_apply_kernel (the builder
 //     emits it in fp32 mode: the old kernel redid norm + swish + expf once per output-channel tile, 12x on the 1536-channel layers);
 //   * weight tiles [16 ci][CO_TILE] stream through a 4-stage ring, three tiles in flight, counted vmcnt + one raw s_barrier per tap;
 //   * the [b][co][t] result leaves through the staged 16-byte epilogue of the split-bf16 kernel (conv_epilogue_staged);
@@ -49,8 +48,10 @@ template <int WPW, int XPW> __device__ __forceinline__ void g_wait_tile(int ahea
 }
 
 // NSW = weight-tile ring stages (4: three tiles in flight; 3: two - 49 KB of LDS with the 96-sample tile, three workgroups per CU)
-template <int WM, int WN, int TM, int TN, bool UPS, int NSW>
-__global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
+// ABL (experiments build, timing only - results are wrong): 1 = no fragment reads, 2 = no DMA, 4 = no barrier, 8 = no MFMAs, 16 = no epilogue
+// NT = taps per phase as a template parameter (0: runtime loop)
+template <int WM, int WN, int TM, int TN, bool UPS, int NSW, int ABL = 0, int NT = 0>
+__global__ void __launch_bounds__(256, 3) conv1d_f32g_kernel(const ConvDev p) {      // three waves per SIMD: <= 168 VGPRs (the unrolled-tap instances of the 128 x 128 tile came out at 171)
     constexpr int CO_TILE = WM * TM * 32;
     constexpr int T_TILE = WN * TN * 32;
     constexpr int XP = (T_TILE + 64 + 63) / 64 * 64;      // window pitch (positions): tile + halo (<= 60) + alignment slack (<= 3)
@@ -120,6 +121,7 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
         xoob |= ok ? 0u : (1u << i);                       // per lane: a bit per piece
     }
     auto issue_x = [&](int ch) {
+        if constexpr (ABL & 2) return;
         const float* src = xbase + (int64_t)ch * GK * p.T_in;
         float* dst = lx + (ch & 1) * XST;
 #pragma unroll
@@ -129,14 +131,41 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
             else __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 256), 16, 0, 0);
         }
     };
-    auto zero_x = [&](int ch) {          // own pieces only, after the wave's own DMA landed: nobody else writes these bytes
-        float* dst = lx + (ch & 1) * XST;
-#pragma unroll
-        for (int i = 0; i < XPW; ++i) {
-            if (!((xoob >> i) & 1)) continue;
-            const int ii = wave * XPW + i;
-            if constexpr (UPS) dst[ii * 64 + lane] = 0.f;
-            else *reinterpret_cast<float4*>(dst + ii * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Once per chunk, by the lanes that DMA'd the quads, after the wave's own DMA has landed and in front of the barrier that publishes the
+    // chunk: zeros over the out-of-range quads (padding) and LeakyReLU IN PLACE - not on the B fragments inside the MFMA loop: v_mul +
+    // 2 v_max per fragment were 6 VALU instructions per 4 MFMAs, and VALU instructions issued between a SIMD's MFMAs cost matrix-pipe
+    // time (tools/probe/f32_loop_probe: 149 -> 136 TF/s with them; here 36 VALU + 6 LDS instructions per thread and chunk replace 48 per
+    // tap).  Same operation on the same values: bit-identical.  The LDS accesses come from inline asm: an ordinary one makes hipcc drain
+    // the DMA ring with vmcnt(0) in front of it (lds_asm.h); the wave has waited for exactly these pieces itself.
+    const bool act = p.in_act == ACT_LRELU;
+    auto fix_x = [&](int ch) {
+        if constexpr (UPS) {
+            const unsigned a0 = lds_u32(lx + (ch & 1) * XST + wave * XPW * 64 + lane);
+            float v[XPW];
+            if (act) {
+                g_static_for<0, XPW>([&](auto ic) { constexpr int I = decltype(ic)::value; lds_rd32<I * 256>(v[I], a0); });
+                LDS_WAIT(0);
+            }
+            g_static_for<0, XPW>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                const bool oob = (xoob >> I) & 1;
+                if (act) { lds_pin(v[I]); lds_wr32<I * 256>(a0, oob ? 0.f : fmaxf(v[I], v[I] * slope)); }
+                else if (oob) lds_wr32<I * 256>(a0, 0.f);
+            });
+        } else {
+            const unsigned a0 = lds_u32(lx + (ch & 1) * XST + wave * XPW * 256 + lane * 4);
+            lds_u32x4 v[XPW];
+            const lds_u32x4 zero = {0u, 0u, 0u, 0u};
+            if (act) {
+                g_static_for<0, XPW>([&](auto ic) { constexpr int I = decltype(ic)::value; lds_rd128<I * 1024>(v[I], a0); });
+                LDS_WAIT(0);
+            }
+            g_static_for<0, XPW>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                const bool oob = (xoob >> I) & 1;
+                if (act) { lds_pin(v[I]); lds_wr128<I * 1024>(a0, oob ? zero : lds_lrelu128_apply(v[I], slope)); }
+                else if (oob) lds_wr128<I * 1024>(a0, zero);
+            });
         }
     };
     // ---- weight DMA: tile (chunk, tap) = 16 rows of CO_TILE floats, 1-KB pieces of 256 / CO_TILE rows
@@ -151,6 +180,7 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
         wsrc[i] = row * p.Co + cog;
     }
     auto issue_w = [&](int ch, int j, int slot) {
+        if constexpr (ABL & 2) return;
         const float* src = wbase + ((int64_t)j * p.Ci + ch * GK) * p.Co;
         float* dst = lw + slot * WT;
 #pragma unroll
@@ -178,35 +208,28 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
         if (t < total) issue_w(nch, nj, t);
         if (++nj == p.ntaps) { nj = 0; ++nch; }
     }
-    int ch = 0, j = 0;                   // tile t = (ch, j)
-    int slot = 0, nslot = NSW - 1;
     float da[TM], dbv[TN];               // held-back operands of a step's last channel pair
 #pragma unroll
     for (int i = 0; i < TM; ++i) da[i] = 0.f;
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) dbv[jn] = 0.f;
-    for (int t = 0; t < total; ++t) {
-        const int ahead_all = min(total - 1, t + NSW - 2) - t;
-        if (j == 0) {
-            // the chunk's window must have landed: it was issued in front of tile (t - ntaps + NSW - 1), so at most min(NSW - 2, ntaps)
-            // younger tiles may fly
-            g_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, p.ntaps), false);
-            if (xoob) { zero_x(ch); __builtin_amdgcn_s_waitcnt(0xc07f); }
-        } else {
-            // window ch + 1 was issued at this chunk's first tap, in front of tile (t - j + NSW - 1): younger than tile t while j <= NSW - 2
-            g_wait_tile<WPW, XPW>(ahead_all, ch + 1 < nchunks && j <= NSW - 2);
-        }
-        __builtin_amdgcn_s_barrier();    // tile t (and the window) landed everywhere; everyone finished tile t - 1
-        if (j == 0 && ch + 1 < nchunks) issue_x(ch + 1);
-        if (t + NSW - 1 < total) issue_w(nch, nj, nslot);
-        // fragments are requested two channel pairs ahead of their MFMAs from inline asm with exact lgkmcnt waits (lds_asm.h: with
-        // LDS-DMA in flight hipcc only ever waits lgkmcnt(0), which exposed one LDS round trip per two pairs); three register sets so
-        // that a request never lands in registers an MFMA in flight still reads; LeakyReLU at use, off the load's path
-        const unsigned xaddr = lds_u32(lx + (ch & 1) * XST + aoff + j * p.dil + wn * TN * 32 + l31 + g * XP);
-        const unsigned waddr = lds_u32(lw + slot * WT + wm * TM * 32 + l31 + g * CO_TILE);
+    // one ring step's multiplications: fragments are requested two channel pairs ahead of their MFMAs from inline asm with exact lgkmcnt
+    // waits (lds_asm.h: with LDS-DMA in flight hipcc only ever waits lgkmcnt(0), which exposed one LDS round trip per two pairs); three
+    // register sets so that a request never lands in registers an MFMA in flight still reads
+    auto multiply = [&](const unsigned xaddr, const unsigned waddr) {
         float a[3][TM], bb[3][TN];
+        if constexpr (ABL & 1) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[s3][i] = (float)lane;
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) bb[s3][jn] = (float)(lane + s3);
+            }
+        }
         auto fload = [&](auto kc) {
             constexpr int KK = decltype(kc)::value, S = KK % 3;
+            if constexpr (ABL & 1) return;
             g_static_for<0, TM>([&](auto ic) { constexpr int I = decltype(ic)::value; lds_rd32<(2 * KK * CO_TILE + I * 32) * 4>(a[S][I], waddr); });
             g_static_for<0, TN>([&](auto jc) { constexpr int J = decltype(jc)::value; lds_rd32<(2 * KK * XP + J * 32) * 4>(bb[S][J], xaddr); });
         };
@@ -220,8 +243,10 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], dbv[jn], acc[i][jn], 0, 0, 0);
+            for (int jn = 0; jn < TN; ++jn) {
+                if constexpr (ABL & 8) acc[i][jn][0] += da[i] * dbv[jn];
+                else acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], dbv[jn], acc[i][jn], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
         g_static_for<0, GK / 2>([&](auto kc) {
             constexpr int KK = decltype(kc)::value, S = KK % 3;
@@ -231,26 +256,81 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn) lds_pin(bb[S][jn]);
             if constexpr (KK + 2 < GK / 2) fload(std::integral_constant<int, KK + 2>{});
-            float bv[TN];
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bv[jn] = fmaxf(bb[S][jn], bb[S][jn] * slope);
             if constexpr (KK + 1 < GK / 2) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < TN; ++jn)
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][i], bv[jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < TN; ++jn) {
+                        if constexpr (ABL & 8) acc[i][jn][0] += a[S][i] * bb[S][jn];
+                        else acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S][i], bb[S][jn], acc[i][jn], 0, 0, 0);
+                    }
             } else {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) da[i] = a[S][i];
 #pragma unroll
-                for (int jn = 0; jn < TN; ++jn) dbv[jn] = bv[jn];
+                for (int jn = 0; jn < TN; ++jn) dbv[jn] = bb[S][jn];
             }
         });
+    };
+    if constexpr (NT > 0) {
+        // ---- the tap count is a template parameter (3 / 7 / 11: the generator's ResBlock layers; the launcher checks p.ntaps == NT): the
+        // taps of a chunk are unrolled, every wait count is an immediate and a step's control flow is the ring-slot update alone.  The
+        // runtime-tap loop below spends ~50 scalar instructions and ~10 branches per step on it, and scalar work between a barrier and
+        // the step's first MFMA costs matrix-pipe time (tools/probe/f32_loop_probe: 151 -> 142 TF/s for ~50 dependent scalar
+        // instructions per 32 MFMAs).  Same tiles in the same order: bit-identical.
+        static_assert(NT >= NSW - 1, "a step issues the tile NSW - 1 ahead: it lies in this chunk or the next one");
+        const unsigned xa0 = lds_u32(lx + aoff + wn * TN * 32 + l31 + g * XP);
+        const unsigned wa0 = lds_u32(lw + wm * TM * 32 + l31 + g * CO_TILE);
+        const int dil4 = p.dil * 4;
+        int slot = 0, nslot = NSW - 1;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const unsigned xa_ch = xa0 + (ch & 1) * (XST * 4);
+            auto chunk = [&](auto lastc) {
+                constexpr bool LAST = decltype(lastc)::value;
+                g_static_for<0, NT>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr int AH = LAST ? (NT - 1 - J < NSW - 2 ? NT - 1 - J : NSW - 2) : NSW - 2;      // younger weight tiles that may fly
+                    if constexpr (J == 0) {
+                        g_wait_vmcnt<(AH < NT ? AH : NT) * WPW>();
+                        if (act || xoob) { fix_x(ch); LDS_WAIT(0); }
+                    } else {
+                        g_wait_vmcnt<AH * WPW + ((!LAST && J <= NSW - 2) ? XPW : 0)>();
+                    }
+                    if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+                    if constexpr (J == 0 && !LAST) issue_x(ch + 1);
+                    if constexpr (J + NSW - 1 < NT) issue_w(ch, J + NSW - 1, nslot);
+                    else if constexpr (!LAST) issue_w(ch + 1, J + NSW - 1 - NT, nslot);
+                    multiply(xa_ch + J * dil4, wa0 + slot * (WT * 4));
+                    if (++slot == NSW) slot = 0;
+                    if (++nslot == NSW) nslot = 0;
+                });
+            };
+            if (ch + 1 == nchunks) chunk(std::true_type{}); else chunk(std::false_type{});
+        }
+    } else {
+    int ch = 0, j = 0;                   // tile t = (ch, j)
+    int slot = 0, nslot = NSW - 1;
+    for (int t = 0; t < total; ++t) {
+        const int ahead_all = min(total - 1, t + NSW - 2) - t;
+        if (j == 0) {
+            // the chunk's window must have landed: it was issued in front of tile (t - ntaps + NSW - 1), so at most min(NSW - 2, ntaps)
+            // younger tiles may fly
+            g_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, p.ntaps), false);
+            if (act || xoob) { fix_x(ch); LDS_WAIT(0); }
+        } else {
+            // window ch + 1 was issued at this chunk's first tap, in front of tile (t - j + NSW - 1): younger than tile t while j <= NSW - 2
+            g_wait_tile<WPW, XPW>(ahead_all, ch + 1 < nchunks && j <= NSW - 2);
+        }
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();    // tile t (and the window) landed everywhere; everyone finished tile t - 1
+        if (j == 0 && ch + 1 < nchunks) issue_x(ch + 1);
+        if (t + NSW - 1 < total) issue_w(nch, nj, nslot);
+        multiply(lds_u32(lx + (ch & 1) * XST + aoff + j * p.dil + wn * TN * 32 + l31 + g * XP),
+                 lds_u32(lw + slot * WT + wm * TM * 32 + l31 + g * CO_TILE));
         if (++j == p.ntaps) { j = 0; ++ch; }
         if (++nj == p.ntaps) { nj = 0; ++nch; }
         if (++slot == NSW) slot = 0;
         if (++nslot == NSW) nslot = 0;
+    }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -258,19 +338,30 @@ __global__ void __launch_bounds__(256) conv1d_f32g_kernel(const ConvDev p) {
         for (int jn = 0; jn < TN; ++jn)
             acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], dbv[jn], acc[i][jn], 0, 0, 0);       // the last step's held-back pair
     __syncthreads();                     // the window ring is free: it holds the four wave-private staging patches now
+    if constexpr (ABL & 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][jn][r];
+        if (sum == 1.2345e-33f) p.out[0] = sum;
+        return;
+    }
     if (p.stage_epi) conv_epilogue_staged<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, lx);
     else conv_epilogue<WM, WN, TM, TN>(p, acc, b, n0, co0, n_count, out_stride, out_off);
 }
 
-template <int WM, int WN, int TM, int TN, bool UPS, int NSW = 4>
+template <int WM, int WN, int TM, int TN, bool UPS, int NSW = 4, int ABL = 0, int NT = 0>
 static void launch_cfg_g(ConvDev& d, int n_count, int B, hipStream_t st) {
     constexpr int CO_TILE = WM * TM * 32, T_TILE = WN * TN * 32, XP = (T_TILE + 64 + 63) / 64 * 64;
     constexpr int BYTES = (2 * GK * XP + NSW * GK * CO_TILE) * (int)sizeof(float);
     d.g_nt = cdiv(n_count, T_TILE); d.g_nco = cdiv(d.Co, CO_TILE);
     d.g_ntb = d.g_nt * B * d.phases; d.g_tbx = cdiv(d.g_ntb, 8);
     static OnceFlags once;
-    vb_set_max_lds_once(once, (const void*)conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW>, BYTES);
-    hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
+    vb_set_max_lds_once(once, (const void*)conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW, ABL, NT>, BYTES);
+    hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW, ABL, NT>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
 }
 // Tile choice for wide layers (Co > 64).  Every configuration walks chunks, taps and channel pairs in the same order - the choice never
 // changes a bit of the result - so it is free to follow the launch's size: the busiest CU's load (workgroups on it x tile area) over a
@@ -290,6 +381,16 @@ static int g_pick_tile(int n_count, int Co, int B, int phases) {
     return best;
 }
 
+// the ResBlock tap counts run the loop with its taps unrolled (template parameter NT); VB_CONV_F32_RT_TAPS=1 keeps the runtime-tap loop
+// (the bit-identity test and the A/B)
+template <int WM, int WN, int TM, int TN, int NSW>
+static void launch_cfg_g_taps(ConvDev& d, int n_count, int B, hipStream_t st) {
+    const int nt = vb_tune().conv_f32_rt_taps ? 0 : d.ntaps;
+    if (nt == 3) launch_cfg_g<WM, WN, TM, TN, false, NSW, 0, 3>(d, n_count, B, st);
+    else if (nt == 7) launch_cfg_g<WM, WN, TM, TN, false, NSW, 0, 7>(d, n_count, B, st);
+    else if (nt == 11) launch_cfg_g<WM, WN, TM, TN, false, NSW, 0, 11>(d, n_count, B, st);
+    else launch_cfg_g<WM, WN, TM, TN, false, NSW>(d, n_count, B, st);
+}
 // picks the tile and launches; the caller (launch_conv1d) has checked the kernel's conditions
 void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream_t st) {
     if (upsample2) {
@@ -298,10 +399,26 @@ void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream
         else launch_cfg_g<2, 2, 2, 2, true, 3>(d, n_count, B, st);
     } else if (d.Co > 64) {
         switch (g_pick_tile(n_count, d.Co, B, d.phases)) {
-            case 1: launch_cfg_g<4, 1, 1, 3, false, 3>(d, n_count, B, st); break;
+            case 1: launch_cfg_g_taps<4, 1, 1, 3, 3>(d, n_count, B, st); break;
             case 2: launch_cfg_g<2, 2, 1, 2, false, 4>(d, n_count, B, st); break;
             case 3: launch_cfg_g<2, 2, 1, 1, false, 3>(d, n_count, B, st); break;
-            default: launch_cfg_g<2, 2, 2, 2, false, 3>(d, n_count, B, st);     // 3-stage ring: 49 KB, three workgroups per CU (31.3 -> 30.4 ms per pass against 4 stages / two)
+            default:
+#ifdef VB_EXPERIMENTS
+                if (const char* e = getenv("VB_F32G_ABL")) {      // timing-only ablations of the 128 x 128 tile (tools/conv_f32_ablate.py)
+                    switch (atoi(e)) {
+                        case 1: launch_cfg_g<2, 2, 2, 2, false, 3, 1>(d, n_count, B, st); return;
+                        case 2: launch_cfg_g<2, 2, 2, 2, false, 3, 2>(d, n_count, B, st); return;
+                        case 4: launch_cfg_g<2, 2, 2, 2, false, 3, 4>(d, n_count, B, st); return;
+                        case 8: launch_cfg_g<2, 2, 2, 2, false, 3, 8>(d, n_count, B, st); return;
+                        case 16: launch_cfg_g<2, 2, 2, 2, false, 3, 16>(d, n_count, B, st); return;
+                        case 3: launch_cfg_g<2, 2, 2, 2, false, 3, 3>(d, n_count, B, st); return;
+                        case 7: launch_cfg_g<2, 2, 2, 2, false, 3, 7>(d, n_count, B, st); return;
+                        case 6: launch_cfg_g<2, 2, 2, 2, false, 3, 6>(d, n_count, B, st); return;
+                        default: break;
+                    }
+                }
+#endif
+                launch_cfg_g_taps<2, 2, 2, 2, 3>(d, n_count, B, st);     // 3-stage ring: 49 KB, three workgroups per CU (31.3 -> 30.4 ms per pass against 4 stages / two)
         }
     } else if (d.Co > 32) launch_cfg_g<2, 2, 1, 2, false>(d, n_count, B, st);
     else launch_cfg_g<1, 4, 1, 2, false>(d, n_count, B, st);

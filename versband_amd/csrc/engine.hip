@@ -46,6 +46,7 @@ static void tune_load() {
     t.band_epi_old = getenv("VB_BAND_EPI_OLD") != nullptr;
     t.conv_f32_old = getenv("VB_CONV_F32_OLD") != nullptr;
     t.gemm_p8_off = getenv("VB_GEMM_P8_OFF") != nullptr;
+    t.conv_f32_rt_taps = getenv("VB_CONV_F32_RT_TAPS") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels

@@ -2243,6 +2243,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
                                                : (a.ldc % 8 == 0 && a.c_noff_group % 8 == 0);
         if (lay && t88 >= P8_MIN_TILES) cfg = 89;
     }
+    // the 192 x 192 tile with the RoPE / V-transpose epilogue needs more registers than a wave has (640 B of scratch at 256 VGPRs): QKV takes the
+    // 128 x 128 tiles wherever the rules above (or VB_GEMM_TILE) say 33 - M in (2176, 2560] rows - bit-identical like every tile choice
+    if (cfg == 33 && a.epi == EPI_QKV_ROPE) cfg = 0;
 #ifdef VB_EXPERIMENTS
     // 8-wave 256 x 256 kernel (variant 4): taken when the problem makes enough of its tiles to occupy a good part of the chip - it
     // moves half the bytes per flop through the L2 -> LDS feed, so it wins even at ~55 % of the CUs busy (12032 x 768: 141 tiles);
@@ -2308,7 +2311,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         case E: \
             if (cfg == 88) { VB_P8_LAUNCH(E) } \
             else if (cfg == 89) launch_p8_product<E>(d, grid, st); \
-            else if (cfg == 33) launch_big<E, 3, 3, 3>(d, grid, st); \
+            else if (cfg == 33) { if constexpr (E != EPI_QKV_ROPE) launch_big<E, 3, 3, 3>(d, grid, st); } \
             else if (cfg == 11) launch_big<E, 1, 1, 3>(d, grid, st); \
             else if (cfg == 21) launch_big<E, 2, 1, 3>(d, grid, st); \
             else launch_t<E>(d, grid, st); \

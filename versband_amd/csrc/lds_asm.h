@@ -33,6 +33,28 @@ template <int OFF> __device__ __forceinline__ void lds_rd128(lds_u32x4& v, unsig
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
 }
 __device__ __forceinline__ void lds_pin(lds_u32x4& v) { asm volatile("" : "+v"(v)); }
+// stores from inline asm: an ordinary LDS access in a kernel with LDS-DMA in flight makes hipcc wait vmcnt(0) in front of it (it must
+// assume the DMA writes the same bytes) - that would drain a counted-vmcnt ring; the kernel has waited for the pieces it touches itself
+template <int OFF> __device__ __forceinline__ void lds_wr128(unsigned addr, const lds_u32x4& v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_write offset is 16 bits");
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_wr32(unsigned addr, float v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_write offset is 16 bits");
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF));
+}
+__device__ __forceinline__ float lds_lrelu_bits(unsigned u, float slope) {
+    const float v = __builtin_bit_cast(float, u);
+    return fmaxf(v, v * slope);
+}
+// LeakyReLU in place on one 16-byte quad
+template <int OFF> __device__ __forceinline__ void lds_lrelu128_request(lds_u32x4& v, unsigned addr) { lds_rd128<OFF>(v, addr); }
+__device__ __forceinline__ lds_u32x4 lds_lrelu128_apply(const lds_u32x4& v, float slope) {
+    lds_u32x4 r;
+    r.x = __builtin_bit_cast(unsigned, lds_lrelu_bits(v.x, slope)); r.y = __builtin_bit_cast(unsigned, lds_lrelu_bits(v.y, slope));
+    r.z = __builtin_bit_cast(unsigned, lds_lrelu_bits(v.z, slope)); r.w = __builtin_bit_cast(unsigned, lds_lrelu_bits(v.w, slope));
+    return r;
+}
 template <int I, int N, class F> __device__ __forceinline__ void lds_static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); lds_static_for<I + 1, N>(f); }
 }

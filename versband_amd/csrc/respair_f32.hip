@@ -12,7 +12,7 @@
 //   * conv1: the raw window of x (128 + (k-1) d positions) arrives by DMA (global_load_lds, 16-B lanes) one 16-channel chunk ahead, the
 //     weight tiles [TPS taps][16 ci][C co] of BOTH convolutions stream through one 3- or 4-stage ring (counted vmcnt, one raw s_barrier per
 //     ring step = TPS taps of a chunk: 32 MFMAs per wave); fragments by inline-asm ds_read_b32 two channel pairs ahead with exact lgkmcnt
-//     (lds_asm.h); LeakyReLU is applied to the B fragment after its read; a wave owns 32 intermediate positions x all channels;
+//     (lds_asm.h); LeakyReLU is applied in place once per chunk by the lanes that DMA'd it; a wave owns 32 intermediate positions x all channels;
 //   * + b1, LeakyReLU, zero outside [0,T) (conv2 pads the ACTIVATED intermediate) -> LDS h[c][m] (aliases the window ring);
 //   * conv2 over h, + b2 + residual x, alpha / beta accumulation into the MRF sum through the staged 16-byte epilogue.
 // Same chunk -> tap -> channel-pair accumulation order and the same epilogue arithmetic as conv1d_f32_kernel / conv1d_f32g_kernel:
@@ -69,7 +69,9 @@ __device__ __forceinline__ float pairf_out_value(const PairF32Dev& p, float acc,
 // C = 32*CH channels; a ring step multiplies TPS taps of one 16-channel chunk (32 MFMAs per wave in every configuration: at 32
 // channels a one-tap step is 8 MFMAs = 512 cycles between two barriers, and the step's fixed costs - barrier, DMA issue, the first
 // fragment round trip - were 40 % of it); NSW ring stages
-template <int CH, int TPS, int NSW>
+// ABL (experiments build, timing only - results are wrong): 1 = no fragment reads, 2 = no DMA, 4 = no ring barriers, 8 = no MFMAs,
+// 16 = no epilogue, 32 = no intermediate write
+template <int CH, int TPS, int NSW, int ABL = 0>
 __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
     constexpr int C = 32 * CH;
     constexpr int XST = PF_GK * PF_XP;                 // floats per window stage
@@ -115,23 +117,35 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
         xoob |= ok ? 0u : (1u << i);
     }
     auto issue_x = [&](int ch) {
+        if constexpr (ABL & 2) return;
         const float* src = xb + (int64_t)ch * PF_GK * p.T;
         float* dst = lx + (ch & 1) * XST;
 #pragma unroll
         for (int i = 0; i < XPW; ++i)
             __builtin_amdgcn_global_load_lds((pf_glb_ptr_t)(src + xsrc[i]), (pf_lds_ptr_t)(dst + (wave * XPW + i) * 256), 16, 0, 0);
     };
-    auto zero_x = [&](int ch) {
-        float* dst = lx + (ch & 1) * XST;
-#pragma unroll
-        for (int i = 0; i < XPW; ++i)
-            if ((xoob >> i) & 1) *reinterpret_cast<float4*>(dst + (wave * XPW + i) * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // once per chunk, by the lanes that DMA'd the quads (after the wave's own DMA landed, in front of the publishing barrier): zeros over
+    // the out-of-range quads and LeakyReLU in place (conv1d_f32g.hip: VALU instructions between a SIMD's MFMAs cost matrix-pipe time; 36 VALU
+    // + 6 LDS instructions per thread and chunk instead of 3 per B fragment; inline-asm LDS accesses so that hipcc does not drain the DMA
+    // ring with vmcnt(0) in front of them).  The residual is read from global memory, not from this window.
+    auto fix_x = [&](int ch) {
+        const unsigned a0 = lds_u32(lx + (ch & 1) * XST + wave * XPW * 256 + lane * 4);
+        lds_u32x4 v[XPW];
+        const lds_u32x4 zero = {0u, 0u, 0u, 0u};
+        pf_static_for<0, XPW>([&](auto ic) { constexpr int I = decltype(ic)::value; lds_rd128<I * 1024>(v[I], a0); });
+        LDS_WAIT(0);
+        pf_static_for<0, XPW>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            lds_pin(v[I]);
+            lds_wr128<I * 1024>(a0, ((xoob >> I) & 1) ? zero : lds_lrelu128_apply(v[I], slope));
+        });
     };
     // ring tile = (convolution, chunk, step): taps [s TPS, s TPS + TPS) of 16 input channels; a tap's [16][C] block is contiguous
     constexpr int NCH = C / PF_GK;
     const int NS = (p.k + TPS - 1) / TPS;             // steps per chunk
     const int NT1 = NCH * NS, total = 2 * NT1;
     auto issue_w = [&](int conv, int ch, int s, int slot) {
+        if constexpr (ABL & 2) return;
         const float* wsrc = conv ? p.w2 : p.w1;
         float* dst = lw + slot * WT;
 #pragma unroll
@@ -166,11 +180,12 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
         const int ahead_all = min(total - 1, t + NSW - 2) - t;
         if (conv == 0 && s == 0) {
             pf_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, NS), false);
-            if (xoob) { zero_x(ch); __builtin_amdgcn_s_waitcnt(0xc07f); }
+            fix_x(ch);
+            LDS_WAIT(0);
         } else {
             pf_wait_tile<WPW, XPW>(ahead_all, conv == 0 && ch + 1 < NCH && s <= NSW - 2);
         }
-        __builtin_amdgcn_s_barrier();    // tile t (and the window) landed everywhere; everyone finished tile t - 1
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();    // tile t (and the window) landed everywhere; everyone finished tile t - 1
         if (conv == 0 && s == 0 && ch + 1 < NCH) issue_x(ch + 1);
         if (t + NSW - 1 < total) issue_w(nconv, nch, ns, nslot);
     };
@@ -192,8 +207,17 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
             baddr[tp] = CONV ? lds_u32(lx + (ch * PF_GK + g) * PF_HP + s * TPS + tp + 32 * wave + l31)
                              : lds_u32(lx + (ch & 1) * XST + g * PF_XP + aoff + (s * TPS + tp) * p.dil + 32 * wave + l31);
         float fa[3][CH], fb[3];
+        if constexpr (ABL & 1) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) fa[s3][i] = (float)lane;
+                fb[s3] = (float)(lane + s);
+            }
+        }
         auto fload = [&](auto mc) {
             constexpr int M = decltype(mc)::value, TP = M / 8, KK = M % 8, S = M % 3;
+            if constexpr (ABL & 1) return;
             pf_static_for<0, CH>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 lds_rd32<((TP * PF_GK + 2 * KK) * C + I * 32) * 4>(fa[S][I], waddr);
@@ -209,9 +233,12 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
             for (int i = 0; i < CH; ++i) lds_pin(fa[S][i]);
             lds_pin(fb[S]);
             if constexpr (M + 2 < NM) fload(std::integral_constant<int, M + 2>{});
-            const float bv = CONV ? fb[S] : fmaxf(fb[S], fb[S] * slope);
+            const float bv = fb[S];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i], bv, acc[i], 0, 0, 0);
+            for (int i = 0; i < CH; ++i) {
+                if constexpr (ABL & 8) acc[i][0] += fa[S][i] * bv;
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S][i], bv, acc[i], 0, 0, 0);
+            }
         });
     };
     auto compute = [&](auto convc) {
@@ -241,7 +268,8 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
                 const int c = i * 32 + 8 * (r >> 2) + 4 * g + (r & 3);
                 float v = acc[i][r] + p.b1[c];
                 v = fmaxf(v, v * p.slope);
-                lx[c * PF_HP + 32 * wave + l31] = inr ? v : 0.f;
+                if constexpr (!(ABL & 32)) lx[c * PF_HP + 32 * wave + l31] = inr ? v : 0.f;
+                else if (v == 1.2345e-33f) lx[c] = v;
                 acc[i][r] = 0.f;
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -259,6 +287,15 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
 
     // ---- epilogue (same two forms as respair_x3_kernel)
     float* ob = p.out + (int64_t)b * p.bstride;
+    if constexpr (ABL & 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[i][r];
+        if (sum == 1.2345e-33f) ob[0] = sum;
+        return;
+    }
     if (p.staged) {
         float* patch = lx + wave * (32 * PF_EP);
         const int rr = lane >> 3, t4 = (lane & 7) * 4;
@@ -319,14 +356,14 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
     }
 }
 
-template <int CH, int TPS, int NSW>
+template <int CH, int TPS, int NSW, int ABL = 0>
 static void launch_pair_f32(const PairF32Dev& d, dim3 grid, hipStream_t st) {
     constexpr int C = 32 * CH, XST = PF_GK * PF_XP;
     constexpr int XH = (2 * XST > C * PF_HP) ? 2 * XST : C * PF_HP;
     constexpr int BYTES = (XH + NSW * TPS * PF_GK * C) * (int)sizeof(float);
     static OnceFlags once;
-    vb_set_max_lds_once(once, (const void*)respair_f32_kernel<CH, TPS, NSW>, BYTES);
-    hipLaunchKernelGGL((respair_f32_kernel<CH, TPS, NSW>), grid, dim3(256), BYTES, st, d);
+    vb_set_max_lds_once(once, (const void*)respair_f32_kernel<CH, TPS, NSW, ABL>, BYTES);
+    hipLaunchKernelGGL((respair_f32_kernel<CH, TPS, NSW, ABL>), grid, dim3(256), BYTES, st, d);
 }
 
 bool respair_f32_supported(const RespairF32Args& a) {
@@ -347,6 +384,28 @@ int launch_respair_f32(const RespairF32Args& a, hipStream_t st) {
     ProfScope prof(3, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T,
                    4.0 * a.B * (double)a.C * a.T * (2.0 + (a.beta != 0.f ? 1.0 : 0.0)) + 2.0 * 4.0 * a.k * a.C * a.C, st);
     // 32 channels: 4 taps per ring step, 3 stages (49 KB: three workgroups per CU); 64: 2 taps, 4 stages (70 KB: two); 128: 1 tap (106 KB: one)
+#ifdef VB_EXPERIMENTS
+    if (const char* e = getenv("VB_PAIRF_ABL")) {          // timing-only ablations (tools/conv_f32_ablate.py)
+        const int v = atoi(e);
+        bool done = true;
+        auto go = [&](auto ablc) {
+            constexpr int A = decltype(ablc)::value;
+            if (a.C == 32) launch_pair_f32<1, 4, 3, A>(d, grid, st); else if (a.C == 64) launch_pair_f32<2, 2, 4, A>(d, grid, st); else done = false;
+        };
+        switch (v) {
+            case 1: go(std::integral_constant<int, 1>{}); break;
+            case 2: go(std::integral_constant<int, 2>{}); break;
+            case 4: go(std::integral_constant<int, 4>{}); break;
+            case 8: go(std::integral_constant<int, 8>{}); break;
+            case 16: go(std::integral_constant<int, 16>{}); break;
+            case 32: go(std::integral_constant<int, 32>{}); break;
+            case 48: go(std::integral_constant<int, 48>{}); break;
+            case 7: go(std::integral_constant<int, 7>{}); break;
+            default: done = false;
+        }
+        if (done) { VB_CHECK_LAUNCH(); return VB_OK; }
+    }
+#endif
     if (a.C == 32) launch_pair_f32<1, 4, 3>(d, grid, st);
     else if (a.C == 64) launch_pair_f32<2, 2, 4>(d, grid, st);
     else launch_pair_f32<4, 1, 4>(d, grid, st);
