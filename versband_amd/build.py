@@ -24,11 +24,14 @@ SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "conv1d_f32g.hip"
 EXPERIMENT_SOURCES = ["score_router.hip"]
 EXPERIMENTS = bool(os.environ.get("VB_BUILD_EXPERIMENTS"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DVB_EXPERIMENTS"] if EXPERIMENTS else [])
-# the exact-fp32 kernels keep their MFMA accumulators in VGPRs (hipcc otherwise copies them to AGPRs and back around every ring step of
-# the asm-pipelined loops: 32 v_accvgpr moves per 32 MFMAs)
-EXTRA_FLAGS = {"conv1d_f32g.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "respair_f32.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
-if not os.environ.get("VB_BUILD_ATTN_AGPR"):
-    EXTRA_FLAGS["attention.hip"] = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# the kernels whose loops read or rescale their MFMA accumulators keep them in VGPRs (hipcc otherwise parks them in AGPRs and copies them
+# to VGPRs and back around every ring step / key tile / window chunk: 32-128 v_accvgpr moves per 8-32 MFMAs, and VALU instructions between a
+# SIMD's MFMAs cost matrix-pipe time).  VB_BUILD_AGPR=a.hip,b.hip builds the named files without the flag (the A/B of round 4).
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+_AGPR = set(filter(None, os.environ.get("VB_BUILD_AGPR", "").split(",")))
+EXTRA_FLAGS = {f: list(_VGPR_FORM) for f in ("conv1d_f32g.hip", "respair_f32.hip", "attention.hip") if f not in _AGPR}
+# (measured without effect on the split-bf16 kernels - conv1d_f32.hip, respair_x3.hip: 28.96 / 14.24 ms per pass with the flag, 28.91 / 14.34 without -
+#  whose accumulator copies sit in the per-chunk window staging, off the critical path; attention: 12.1 -> 10.9 ms per pass)
 MARKER = b"VB_SOURCE_DIGEST="
 PUBLIC_HEADER = os.path.join(HERE, "..", "include", "versband_hip.h")
 
