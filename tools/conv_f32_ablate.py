@@ -33,7 +33,7 @@ def timed(run, n=6):
 
 torch.manual_seed(0)
 print("== conv1d_f32g_kernel<2,2,2,2,false,3> (128 x 128 tile): VB_F32G_ABL")
-G_ABL = [("full", None), ("noFrag", 1), ("noDMA", 2), ("noBar", 4), ("noMFMA", 8), ("noEpi", 16), ("noFrag+DMA", 3), ("noDMA+Bar", 6), ("MFMA only", 7)]
+G_ABL = [("full", None), ("full", None), ("noFrag", 1), ("noDMA", 2), ("noBar", 4), ("noMFMA", 8), ("noEpi", 16), ("noFrag+DMA", 3), ("noDMA+Bar", 6), ("MFMA only", 7)]
 for C, T, k, dil in ((256, 12032, 7, 3), (256, 12032, 3, 1), (128, 60160, 7, 3), (128, 60160, 11, 5)):
     x = torch.randn(B, C, T, device="cuda")
     w = torch.randn(C, C, k) / (C * k) ** 0.5
@@ -55,6 +55,11 @@ for C, T, k, dil in ((256, 12032, 7, 3), (256, 12032, 3, 1), (128, 60160, 7, 3),
             os.environ["VB_F32G_ABL"] = str(v)
         line += f"  {name} {timed(run):6.0f}"
     os.environ.pop("VB_F32G_ABL", None)
+    for tv in ("2", "3"):
+        os.environ["VB_F32G_TILE"] = tv
+        line += f"  tile{tv} {timed(run):6.0f}"
+    os.environ.pop("VB_F32G_TILE", None)
+    line += f"  full {timed(run):6.0f}"
     print(line, flush=True)
 
 print("== respair_f32_kernel: VB_PAIRF_ABL")

@@ -398,6 +398,12 @@ void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream
         if (cdiv(w96, 256) * 96 < cdiv(w128, 256) * 128) launch_cfg_g<4, 1, 1, 3, true, 3>(d, n_count, B, st);
         else launch_cfg_g<2, 2, 2, 2, true, 3>(d, n_count, B, st);
     } else if (d.Co > 64) {
+#ifdef VB_EXPERIMENTS
+        if (const char* e = getenv("VB_F32G_TILE")) {       // tile shapes measured and not adopted
+            if (atoi(e) == 2) { launch_cfg_g_taps<2, 2, 1, 2, 3>(d, n_count, B, st); return; }      // 64 x 128, 3 stages: 36.5 KB, four workgroups per CU
+            if (atoi(e) == 3) { launch_cfg_g_taps<1, 4, 2, 1, 3>(d, n_count, B, st); return; }      // 64 x 128 as 1 x 4 waves of 2 x 1 tiles
+        }
+#endif
         switch (g_pick_tile(n_count, d.Co, B, d.phases)) {
             case 1: launch_cfg_g_taps<4, 1, 1, 3, 3>(d, n_count, B, st); break;
             case 2: launch_cfg_g<2, 2, 1, 2, false, 4>(d, n_count, B, st); break;

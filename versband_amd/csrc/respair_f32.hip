@@ -11,7 +11,7 @@
 // TT = 128 - (k-1) output samples of ALL channels and the intermediate never leaves LDS:
 //   * conv1: the raw window of x (128 + (k-1) d positions) arrives by DMA (global_load_lds, 16-B lanes) one 16-channel chunk ahead, the
 //     weight tiles [TPS taps][16 ci][C co] of BOTH convolutions stream through one 3- or 4-stage ring (counted vmcnt, one raw s_barrier per
-//     ring step = TPS taps of a chunk: 32 MFMAs per wave); fragments by inline-asm ds_read_b32 two channel pairs ahead with exact lgkmcnt
+//     ring step = TPS taps of a chunk: 32 / 16 MFMAs per wave at 32 / 64 channels); fragments by inline-asm ds_read_b32 two channel pairs ahead with exact lgkmcnt
 //     (lds_asm.h); LeakyReLU is applied in place once per chunk by the lanes that DMA'd it; a wave owns 32 intermediate positions x all channels;
 //   * + b1, LeakyReLU, zero outside [0,T) (conv2 pads the ACTIVATED intermediate) -> LDS h[c][m] (aliases the window ring);
 //   * conv2 over h, + b2 + residual x, alpha / beta accumulation into the MRF sum through the staged 16-byte epilogue.
@@ -66,9 +66,9 @@ __device__ __forceinline__ float pairf_out_value(const PairF32Dev& p, float acc,
     return fmaf(val, p.alpha, p.beta * old);
 }
 
-// C = 32*CH channels; a ring step multiplies TPS taps of one 16-channel chunk (32 MFMAs per wave in every configuration: at 32
-// channels a one-tap step is 8 MFMAs = 512 cycles between two barriers, and the step's fixed costs - barrier, DMA issue, the first
-// fragment round trip - were 40 % of it); NSW ring stages
+// C = 32*CH channels; a ring step multiplies TPS taps of one 16-channel chunk (at 32 channels a one-tap step is 8 MFMAs = 512 cycles
+// between two barriers, and the step's fixed costs - barrier, DMA issue, the first fragment round trip - were 40 % of it: four taps,
+// 32 MFMAs; at 64 channels one tap = 16 MFMAs keeps the workgroup at 49 KB of LDS, see launch_respair_f32); NSW ring stages
 // ABL (experiments build, timing only - results are wrong): 1 = no fragment reads, 2 = no DMA, 4 = no ring barriers, 8 = no MFMAs,
 // 16 = no epilogue, 32 = no intermediate write
 template <int CH, int TPS, int NSW, int ABL = 0>
@@ -383,7 +383,10 @@ int launch_respair_f32(const RespairF32Args& a, hipStream_t st) {
     dim3 grid(cdiv(a.T, TT), 1, a.B);
     ProfScope prof(3, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T,
                    4.0 * a.B * (double)a.C * a.T * (2.0 + (a.beta != 0.f ? 1.0 : 0.0)) + 2.0 * 4.0 * a.k * a.C * a.C, st);
-    // 32 channels: 4 taps per ring step, 3 stages (49 KB: three workgroups per CU); 64: 2 taps, 4 stages (70 KB: two); 128: 1 tap (106 KB: one)
+    // 32 channels: 4 taps per ring step, 3 stages (49 KB: three workgroups per CU).  64 channels: ONE tap per step, 3 stages - 49 KB, three
+    // workgroups per CU: 16 MFMAs per step and wave instead of 32, but a third wave per SIMD: 2046 -> 1787 us at k = 7, 3181 -> 2799 at k = 11,
+    // 994 -> 850 at k = 3 (8 clips; two taps / 4 stages = 70 KB = two per CU was the first shape; four per CU at 32 channels measured
+    // 1 % slower: tools/pair_cfg_bench.py).  128 channels: 1 tap, 106 KB, one per CU - not used by the builder.
 #ifdef VB_EXPERIMENTS
     if (const char* e = getenv("VB_PAIRF_ABL")) {          // timing-only ablations (tools/conv_f32_ablate.py)
         const int v = atoi(e);
@@ -406,8 +409,18 @@ int launch_respair_f32(const RespairF32Args& a, hipStream_t st) {
         if (done) { VB_CHECK_LAUNCH(); return VB_OK; }
     }
 #endif
+#ifdef VB_EXPERIMENTS
+    if (const char* e = getenv("VB_PAIRF_CFG")) {           // ring shapes measured and not adopted (tools/conv_f32_ablate.py)
+        const int v = atoi(e);
+        if (a.C == 64 && v == 1) { launch_pair_f32<2, 1, 4>(d, grid, st); VB_CHECK_LAUNCH(); return VB_OK; }     // 53 KB: three workgroups per CU, one tap per step
+        if (a.C == 64 && v == 2) { launch_pair_f32<2, 1, 3>(d, grid, st); VB_CHECK_LAUNCH(); return VB_OK; }     // 49 KB
+        if (a.C == 32 && v == 3) { launch_pair_f32<1, 2, 4>(d, grid, st); VB_CHECK_LAUNCH(); return VB_OK; }
+        if (a.C == 32 && v == 4) { launch_pair_f32<1, 2, 3>(d, grid, st); VB_CHECK_LAUNCH(); return VB_OK; }     // 36.5 KB: four workgroups per CU
+        if (a.C == 64 && v == 5) { launch_pair_f32<2, 2, 4>(d, grid, st); VB_CHECK_LAUNCH(); return VB_OK; }     // round-4 shape: 70 KB, two per CU
+    }
+#endif
     if (a.C == 32) launch_pair_f32<1, 4, 3>(d, grid, st);
-    else if (a.C == 64) launch_pair_f32<2, 2, 4>(d, grid, st);
+    else if (a.C == 64) launch_pair_f32<2, 1, 3>(d, grid, st);
     else launch_pair_f32<4, 1, 4>(d, grid, st);
     VB_CHECK_LAUNCH();
     return VB_OK;
