@@ -438,7 +438,9 @@ def test_fp32_dma_conv_transpose_is_bit_identical(lib, monkeypatch, B, Ci, T, Co
 
 @pytest.mark.parametrize("B,C,T,k,dil,alpha,beta", [(2, 32, 1000, 3, 1, 1.0, 0.0), (1, 32, 472, 11, 5, 1.0 / 3, 1.0), (2, 64, 600, 7, 3, 1.0, 0.0),
                                                    (1, 64, 244, 11, 5, 1.0 / 3, 1.0), (1, 64, 128, 3, 5, 1.0 / 3, 0.0),
-                                                   (1, 128, 360, 7, 1, 1.0, 0.0), (2, 128, 120, 11, 3, 1.0 / 3, 1.0)])
+                                                   (1, 128, 360, 7, 1, 1.0, 0.0), (2, 128, 120, 11, 3, 1.0 / 3, 1.0),
+                                                   (2, 32, 1000, 7, 3, 1.0, 0.0), (1, 32, 360, 5, 1, 1.0, 0.0), (2, 64, 372, 3, 1, 1.0, 0.0),
+                                                   (1, 64, 500, 5, 3, 1.0, 0.0)])
 def test_fp32_respair_equals_two_fp32_convolutions(lib, B, C, T, k, dil, alpha, beta):
     """respair_f32_kernel (vocoder/hifigan/modules/hifigan.py:27-64 ResBlock1 pair, intermediate kept in LDS) against the two launches
     of the fp32 convolution kernel it replaces: same accumulation order, same epilogue arithmetic - equal bit for bit (torch.equal
@@ -461,6 +463,32 @@ def test_fp32_respair_equals_two_fp32_convolutions(lib, B, C, T, k, dil, alpha, 
     assert rel_l2(fused, ref64) < 2e-6, describe("respair fp32", fused, ref64)
     if alpha == 1.0 and beta == 0.0:
         assert torch.equal(fused, t2), f"fused pair vs two launches differ by {float((fused - t2).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("C,k,dil", [(32, 7, 3), (32, 11, 5), (64, 3, 1), (64, 7, 3), (64, 11, 5)])
+def test_fp32_respair_unrolled_control_flow_equals_the_runtime_loop(lib, monkeypatch, C, k, dil):
+    """respair_f32_kernel with the kernel size as a template parameter (a chunk's steps unrolled, wait counts / tap offsets / the tile to
+    request as immediates) against its runtime loop (VB_CONV_F32_RT_TAPS=1): same tiles in the same order - the same bits, incl. both clip
+    ends and the accumulate form."""
+    B, T = 2, 1100
+    x = dev(rnd((B, C, T), "qx"))
+    p1, p2 = dev(pack.pack_conv(rnd((C, C, k), "qw1", 1.0 / (C * k) ** 0.5))), dev(pack.pack_conv(rnd((C, C, k), "qw2", 1.0 / (C * k) ** 0.5)))
+    b1, b2 = dev(rnd((C,), "qb1")), dev(rnd((C,), "qb2"))
+    acc0 = dev(rnd((B, C, T), "qacc"))
+
+    def run():
+        out = acc0.clone()
+        L.check(lib.vb_respair_f32(L.ptr(x), L.ptr(p1), L.ptr(b1), L.ptr(p2), L.ptr(b2), B, C, T, k, dil, 0.1, 1.0 / 3, 1.0, L.ptr(out),
+                                   L.stream_ptr()), "respair_f32")
+        sync()
+        return out
+    new = run()
+    monkeypatch.setenv("VB_CONV_F32_RT_TAPS", "1")
+    lib.vb_tune_reload()
+    old = run()
+    monkeypatch.delenv("VB_CONV_F32_RT_TAPS")
+    lib.vb_tune_reload()
+    assert torch.isfinite(new).all() and torch.equal(new, old), f"unrolled vs runtime loop differ by {float((new - old).abs().max()):.3e}"
 
 
 def test_fp32_vocoder_fused_pairs_equal_unfused_launches(lib, monkeypatch):

@@ -19,7 +19,7 @@ template <int I, int N, class F> __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
 }
 
-template <int FEAT>
+template <int FEAT, int NP = 8>      // NP channel pairs per step: 8 = 32 MFMAs (the convolution kernel, 32-channel pairs), 4 = 16 (64-channel pairs)
 __global__ void __launch_bounds__(256) loop_kernel(float* out, int steps, float slope_in, int salt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,19 +72,19 @@ __global__ void __launch_bounds__(256) loop_kernel(float* out, int steps, float 
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(da[i], db[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        sfor<0, 8>([&](auto kc) {
+        sfor<0, NP>([&](auto kc) {
             constexpr int KK = decltype(kc)::value, S = KK % 3;
             if constexpr (FEAT & 2) {
-                if constexpr (KK + 1 < 8) LDS_WAIT(4); else LDS_WAIT(0);
+                if constexpr (KK + 1 < NP) LDS_WAIT(4); else LDS_WAIT(0);
                 lds_pin(a[S][0]); lds_pin(a[S][1]); lds_pin(b[S][0]); lds_pin(b[S][1]);
             } else {
                 asm volatile("" : "+v"(a[S][0]), "+v"(a[S][1]), "+v"(b[S][0]), "+v"(b[S][1]));       // operands "change" every pair
             }
-            if constexpr (KK + 2 < 8) fload(std::integral_constant<int, KK + 2>{});
+            if constexpr (KK + 2 < NP) fload(std::integral_constant<int, KK + 2>{});
             float bv[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bv[j] = (FEAT & 1) ? fmaxf(b[S][j], b[S][j] * slope) : b[S][j];
-            if constexpr ((FEAT & 16) && KK == 7) {
+            if constexpr ((FEAT & 16) && KK == NP - 1) {
                 da[0] = a[S][0]; da[1] = a[S][1]; db[0] = bv[0]; db[1] = bv[1];
             } else {
 #pragma unroll
@@ -99,15 +99,15 @@ __global__ void __launch_bounds__(256) loop_kernel(float* out, int steps, float 
     out[blockIdx.x * 256 + tid] = sum + da[0] + db[0];
 }
 
-template <int FEAT>
+template <int FEAT, int NP = 8>
 static void run(float* out, const char* what, int blocks, int lds_bytes) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)loop_kernel<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    const int steps = 4000;
-    loop_kernel<FEAT><<<blocks, 256, lds_bytes>>>(out, 50, 0.1f, 3);
-    hipEventRecord(e0); loop_kernel<FEAT><<<blocks, 256, lds_bytes>>>(out, steps, 0.1f, 3); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipFuncSetAttribute((const void*)loop_kernel<FEAT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    const int steps = 4000 * 8 / NP;
+    loop_kernel<FEAT, NP><<<blocks, 256, lds_bytes>>>(out, 50, 0.1f, 3);
+    hipEventRecord(e0); loop_kernel<FEAT, NP><<<blocks, 256, lds_bytes>>>(out, steps, 0.1f, 3); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double nm = (FEAT & 16) ? 32.0 : 32.0;
+    const double nm = 4.0 * NP;
     const double fl = (double)blocks * 4 * steps * nm * 2.0 * 32 * 32 * 2;
     printf("%-44s %4d blocks (%d KB LDS): %6.1f TFLOP/s\n", what, blocks, lds_bytes / 1024, fl / ms / 1e9);
 }
@@ -132,5 +132,12 @@ int main() {
         run<46>(out, "+ ds_reads + barrier + scalar + branches", blocks, lb);
         run<22>(out, "+ ds_reads + barrier + deferred pair", blocks, lb);
     }
+    printf("-- 16 MFMAs per step (4 channel pairs), three workgroups per CU\n");
+    run<6, 4>(out, "ds_reads + barrier", 768, 49152);
+    run<14, 4>(out, "+ scalar", 768, 49152);
+    run<38, 4>(out, "+ branches", 768, 49152);
+    run<46, 4>(out, "+ scalar + branches", 768, 49152);
+    run<22, 4>(out, "ds_reads + barrier + deferred pair", 768, 49152);
+    run<62, 4>(out, "+ scalar + branches + deferred pair", 768, 49152);
     return 0;
 }

@@ -71,7 +71,8 @@ __device__ __forceinline__ float pairf_out_value(const PairF32Dev& p, float acc,
 // 32 MFMAs; at 64 channels one tap = 16 MFMAs keeps the workgroup at 49 KB of LDS, see launch_respair_f32); NSW ring stages
 // ABL (experiments build, timing only - results are wrong): 1 = no fragment reads, 2 = no DMA, 4 = no ring barriers, 8 = no MFMAs,
 // 16 = no epilogue, 32 = no intermediate write
-template <int CH, int TPS, int NSW, int ABL = 0>
+// K = kernel size as a template parameter (3 / 7 / 11; 0 = runtime): see the unrolled control flow below
+template <int CH, int TPS, int NSW, int ABL = 0, int K = 0>
 __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
     constexpr int C = 32 * CH;
     constexpr int XST = PF_GK * PF_XP;                 // floats per window stage
@@ -197,22 +198,20 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
     };
     // one ring step: up to TPS taps x 8 channel pairs, fragments requested two pairs ahead of their MFMAs (lds_asm.h), three
     // register sets so that a request never lands in registers an MFMA in flight still reads
-    auto body = [&](auto convc, auto ntc) {
+    // (waddr: this lane's byte address in the step's weight tile; b0: ... of the step's first tap in the window / intermediate; bstep: bytes per tap)
+    auto body = [&](auto convc, auto ntc, const unsigned waddr, const unsigned b0, const unsigned bstep) {
         constexpr int CONV = decltype(convc)::value, NM = decltype(ntc)::value * 8;       // channel pairs of this step: compile-time,
         constexpr int PITCH = CONV ? PF_HP : PF_XP;                                          // so every wait count below is an immediate
-        const unsigned waddr = lds_u32(lw + slot * WT + l31 + g * C);
         unsigned baddr[TPS];
 #pragma unroll
-        for (int tp = 0; tp < TPS; ++tp)
-            baddr[tp] = CONV ? lds_u32(lx + (ch * PF_GK + g) * PF_HP + s * TPS + tp + 32 * wave + l31)
-                             : lds_u32(lx + (ch & 1) * XST + g * PF_XP + aoff + (s * TPS + tp) * p.dil + 32 * wave + l31);
+        for (int tp = 0; tp < TPS; ++tp) baddr[tp] = b0 + tp * bstep;
         float fa[3][CH], fb[3];
         if constexpr (ABL & 1) {
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) fa[s3][i] = (float)lane;
-                fb[s3] = (float)(lane + s);
+                fb[s3] = (float)(lane + s3);
             }
         }
         auto fload = [&](auto mc) {
@@ -242,23 +241,18 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
         });
     };
     auto compute = [&](auto convc) {
+        constexpr int CONV = decltype(convc)::value;
         const int ntap = min(TPS, p.k - s * TPS);       // taps of this step (the last step of a chunk may hold fewer)
+        const unsigned waddr = lds_u32(lw + slot * WT + l31 + g * C);
+        const unsigned b0 = CONV ? lds_u32(lx + (ch * PF_GK + g) * PF_HP + s * TPS + 32 * wave + l31)
+                                 : lds_u32(lx + (ch & 1) * XST + g * PF_XP + aoff + s * TPS * p.dil + 32 * wave + l31);
         pf_static_for<1, TPS + 1>([&](auto ntc) {
-            if (ntap == decltype(ntc)::value) body(convc, ntc);
+            if (ntap == decltype(ntc)::value) body(convc, ntc, waddr, b0, CONV ? 4u : (unsigned)(p.dil * 4));
         });
     };
-
-    // ---- conv1 (dilated) over the activated window -> intermediate positions m0 + [0,128)
-    int t = 0;
-    for (; t < NT1; ++t) {
-        pre(t);
-        compute(std::integral_constant<int, 0>{});
-        advance();
-    }
-    // ---- between the convolutions: every wave is past conv1's last tile once it crosses the barrier of pre(): the window ring is dead.
-    // + b1, LeakyReLU, zero outside [0,T), to h[c][m]; a second barrier publishes it
-    pre(t);
-    {
+    // + b1, LeakyReLU, zero outside [0,T), to h[c][m] (the window ring is dead: every wave is past conv1's last tile once it has crossed
+    // the barrier of the first conv2 tile's step); a second barrier publishes it
+    auto middle = [&]() {
         const int m = m0 + 32 * wave + l31;
         const bool inr = m >= 0 && m < p.T;
 #pragma unroll
@@ -274,7 +268,65 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
+    };
+    if constexpr (K > 0) {
+        // ---- kernel size as a template parameter (the launcher checks p.k == K): a chunk's NS steps are unrolled, every wait count, tap
+        // offset and "which tile to request" is an immediate, and a step's control flow is the ring-slot update alone.  The runtime
+        // loop below spends ~50 scalar instructions and ~10 branches per step on it - at 16-32 MFMAs per step that costs up to 18 % of
+        // the matrix pipe (tools/probe/f32_loop_probe: 147 -> 121 TF/s at 16 MFMAs per step).  Same tiles in the same order: bit-identical.
+        constexpr int KNS = (K + TPS - 1) / TPS;
+        static_assert(KNS >= NSW - 1, "a step requests the tile NSW - 1 ahead: it lies in this chunk or the next one");
+        const unsigned wa0 = lds_u32(lw + l31 + g * C);
+        const unsigned xa0 = lds_u32(lx + g * PF_XP + aoff + 32 * wave + l31);
+        const unsigned ha0 = lds_u32(lx + g * PF_HP + 32 * wave + l31);
+        const unsigned dil4 = (unsigned)(p.dil * 4);
+        int slot_b = 0, nslot = NSW - 1;                 // byte offset of tile t's ring slot; slot index of tile t + NSW - 1
+        auto chunk = [&](auto convc, auto lastc, auto firstc, const int ch) {
+            constexpr int CONV = decltype(convc)::value;
+            constexpr bool LASTCH = decltype(lastc)::value, FIRST1 = decltype(firstc)::value;      // last chunk of this convolution; conv2's first chunk
+            const unsigned bch = CONV ? ha0 + ch * (PF_GK * PF_HP * 4) : xa0 + (ch & 1) * (XST * 4);
+            pf_static_for<0, KNS>([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                constexpr int AH = (CONV == 1 && LASTCH) ? (KNS - 1 - S < NSW - 2 ? KNS - 1 - S : NSW - 2) : NSW - 2;   // younger weight tiles that may fly
+                if constexpr (CONV == 0 && S == 0) {
+                    pf_wait_vmcnt<(AH < KNS ? AH : KNS) * WPW>();
+                    fix_x(ch);
+                    LDS_WAIT(0);
+                } else {
+                    pf_wait_vmcnt<AH * WPW + ((CONV == 0 && !LASTCH && S <= NSW - 2) ? XPW : 0)>();
+                }
+                if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+                if constexpr (CONV == 0 && S == 0 && !LASTCH) issue_x(ch + 1);
+                constexpr int SN = S + NSW - 1;
+                if constexpr (SN < KNS) issue_w(CONV, ch, SN, nslot);
+                else if constexpr (!LASTCH) issue_w(CONV, ch + 1, SN - KNS, nslot);
+                else if constexpr (CONV == 0) issue_w(1, 0, SN - KNS, nslot);
+                if constexpr (FIRST1 && S == 0) middle();
+                constexpr int NTAP = (K - S * TPS) < TPS ? (K - S * TPS) : TPS;
+                body(convc, std::integral_constant<int, NTAP>{}, wa0 + slot_b, bch + (CONV ? (unsigned)(S * TPS * 4) : (unsigned)(S * TPS) * dil4),
+                     CONV ? 4u : dil4);
+                slot_b = slot_b == (NSW - 1) * WT * 4 ? 0 : slot_b + WT * 4;
+                if (++nslot == NSW) nslot = 0;
+            });
+        };
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        for (int c = 0; c < NCH - 1; ++c) chunk(C0{}, std::false_type{}, std::false_type{}, c);
+        chunk(C0{}, std::true_type{}, std::false_type{}, NCH - 1);
+        chunk(C1{}, std::false_type{}, std::true_type{}, 0);
+        for (int c = 1; c < NCH - 1; ++c) chunk(C1{}, std::false_type{}, std::false_type{}, c);
+        chunk(C1{}, std::true_type{}, std::false_type{}, NCH - 1);
+    } else {
+
+    // ---- conv1 (dilated) over the activated window -> intermediate positions m0 + [0,128)
+    int t = 0;
+    for (; t < NT1; ++t) {
+        pre(t);
+        compute(std::integral_constant<int, 0>{});
+        advance();
     }
+    // ---- between the convolutions
+    pre(t);
+    middle();
     // ---- conv2 (dil 1) over the intermediate -> outputs n0 + [0,TT)
     compute(std::integral_constant<int, 1>{});
     advance();
@@ -282,6 +334,7 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
         pre(t);
         compute(std::integral_constant<int, 1>{});
         advance();
+    }
     }
     __syncthreads();                     // h is dead: its storage holds the four wave-private staging patches now
 
@@ -356,14 +409,14 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
     }
 }
 
-template <int CH, int TPS, int NSW, int ABL = 0>
+template <int CH, int TPS, int NSW, int ABL = 0, int K = 0>
 static void launch_pair_f32(const PairF32Dev& d, dim3 grid, hipStream_t st) {
     constexpr int C = 32 * CH, XST = PF_GK * PF_XP;
     constexpr int XH = (2 * XST > C * PF_HP) ? 2 * XST : C * PF_HP;
     constexpr int BYTES = (XH + NSW * TPS * PF_GK * C) * (int)sizeof(float);
     static OnceFlags once;
-    vb_set_max_lds_once(once, (const void*)respair_f32_kernel<CH, TPS, NSW, ABL>, BYTES);
-    hipLaunchKernelGGL((respair_f32_kernel<CH, TPS, NSW, ABL>), grid, dim3(256), BYTES, st, d);
+    vb_set_max_lds_once(once, (const void*)respair_f32_kernel<CH, TPS, NSW, ABL, K>, BYTES);
+    hipLaunchKernelGGL((respair_f32_kernel<CH, TPS, NSW, ABL, K>), grid, dim3(256), BYTES, st, d);
 }
 
 bool respair_f32_supported(const RespairF32Args& a) {
@@ -419,9 +472,19 @@ int launch_respair_f32(const RespairF32Args& a, hipStream_t st) {
         if (a.C == 64 && v == 5) { launch_pair_f32<2, 2, 4>(d, grid, st); VB_CHECK_LAUNCH(); return VB_OK; }     // round-4 shape: 70 KB, two per CU
     }
 #endif
-    if (a.C == 32) launch_pair_f32<1, 4, 3>(d, grid, st);
-    else if (a.C == 64) launch_pair_f32<2, 1, 3>(d, grid, st);
-    else launch_pair_f32<4, 1, 4>(d, grid, st);
+    // the generator's kernel sizes run the unrolled control flow (template parameter K) where a chunk has at least NSW - 1 steps;
+    // VB_CONV_F32_RT_TAPS=1 keeps the runtime loop (the bit-identity test and the A/B)
+    const int kk = vb_tune().conv_f32_rt_taps ? 0 : a.k;
+    if (a.C == 32) {
+        if (kk == 7) launch_pair_f32<1, 4, 3, 0, 7>(d, grid, st);
+        else if (kk == 11) launch_pair_f32<1, 4, 3, 0, 11>(d, grid, st);
+        else launch_pair_f32<1, 4, 3>(d, grid, st);            // (k = 3 is one step per chunk at four taps per step)
+    } else if (a.C == 64) {
+        if (kk == 3) launch_pair_f32<2, 1, 3, 0, 3>(d, grid, st);
+        else if (kk == 7) launch_pair_f32<2, 1, 3, 0, 7>(d, grid, st);
+        else if (kk == 11) launch_pair_f32<2, 1, 3, 0, 11>(d, grid, st);
+        else launch_pair_f32<2, 1, 3>(d, grid, st);
+    } else launch_pair_f32<4, 1, 4>(d, grid, st);
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
