@@ -1708,6 +1708,491 @@ static void launch_big(const GemmDev& d, dim3 grid, hipStream_t st) {
     hipLaunchKernelGGL((gemm_bf16_big_kernel<EPI, TM, TN, NSTB>), grid, dim3(NTHREADS), lds, st, d);
 }
 
+#ifdef VB_EXPERIMENTS
+// ---- variant 5 (round 5): PERSISTENT 8-wave kernel - one workgroup per CU walks a balanced share of the launch ------------------------
+// What the 256 x 256 kernel above (variant 4) loses, by its own ablations (profiles/r02_gemm_p8_microbench.txt): a third of every
+// launch is the epilogue of a tile with nothing beside it (one workgroup per CU: 61.0 -> 39.7 us without it at 12032 x 2304 x 768),
+// the tile grid is quantised (423 tiles on 256 CUs = two rounds for 1.65 rounds of work), every tile starts with a cold ring, and a
+// 32-deep stage makes every DMA instruction touch 16 HALF lines (64 of a row's 128 bytes): each 128-B line crosses the CU's 64 B/clk
+// L1 fill path twice, 1.57 MB per 100-MFLOP tile = 24.6k cycles - as long as the tile's MFMAs.  This kernel
+//   * is launched ONCE per CU.  The rows are cut into 64-row units; XCD x owns the units [U x/8, U (x+1)/8) for all column tiles, its
+//     workgroups split that (column tile, unit) range - column-major - into equal contiguous shares (+-1 unit).  A share is walked as
+//     tiles of 1..4 units x 256 columns (IM = units: a wave row owns IM 32-row MFMA blocks), cut at column-tile and row-group ends;
+//   * keeps ONE DMA ring running across tile boundaries: stages are 64 deep (a DMA instruction = 8 rows x one full 128-B line), the
+//     ring has five 32-KB slots holding the items A0 B0 A1 B1 .. (item q -> slot q mod 5); while stage s is multiplied, B(s+1) and
+//     A(s+2) are issued into the two slots stage s-1 left: 1.5 stages (96 KB) in flight, the next tile's first stages arrive under
+//     the current tile's last MFMAs, and the stage-end wait is the counted vmcnt(4) + one barrier;
+//   * stores a tile straight from the accumulators in the P16 layout (no LDS staging - the ring never stops) and goes on: the stores
+//     drain under the next tile's MFMAs.  vmcnt counts loads AND stores in issue order per kind; stores between the DMA items only
+//     make a counted wait more conservative, never less (loads retire in order among themselves);
+//   * writes the V third of QKV with the MFMA's operands exchanged (tokens as the row operand, P16 permutation on the TOKEN rows): a
+//     lane owns one head-dim column and 16 consecutive tokens = the V^T image's 32 contiguous bytes, the same instruction operand
+//     roles as the 4-wave kernel's V tiles.
+// Per output element the products are accumulated in the same order as in every other variant (k ascending, 16 per MFMA): bit-identical.
+struct PkTile { int g, row0, rows_end, n0, im; bool valid; };
+
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_vt_pk(const GemmDev& p, f32x16 (&acc)[TM][TN], int tok_base, int rows_end, int n_base, int frow, int fk) {
+    // acc[i][j][e]: token tok_base + i*32 + 16*fk + e, projection column n_base + j*32 + frow (see the note above)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 32 + frow;
+        if (n >= p.N) continue;
+        const int nn = n - 2 * p.D;
+        const int h = fdiv(nn, p.rhd), d = nn - h * p.hd;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m0 = tok_base + i * 32 + 16 * fk;
+            if (m0 >= rows_end) continue;
+            const int b = fdiv(m0, p.rT), t = m0 - b * p.T;
+            const int64_t base = ((int64_t)(b * p.H + h) * p.hd + d) * p.Tpad + t;
+            float o[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = acc[i][j][e];
+            if (m0 + 15 < rows_end) {
+                store8p(p.vt, p.vt_plane, p.qkv_np, base, o);
+                store8p(p.vt, p.vt_plane, p.qkv_np, base + 8, o + 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (m0 + e < rows_end) store1p(p.vt, p.vt_plane, p.qkv_np, base + e, o[e]);
+            }
+        }
+    }
+}
+
+// q / k thirds of QKV + RoPE in the P16 layout: wave_epilogue_qkv_p16 without its V branch (the persistent kernel writes V tiles with
+// wave_epilogue_vt_pk; the launcher takes it only where that form applies) - the 16 two-byte V^T stores of that branch cost 32 address
+// registers the tile loop's own state has no room for.  Same arithmetic, element for element.
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_qk_p16(const GemmDev& p, f32x16 (&acc)[TM][TN], int row_base, int rows_end, int n_base, int frow, int fk) {
+#pragma clang fp contract(off)
+    const int hd2 = p.hd >> 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = row_base + i * 32 + frow;
+        if (m < rows_end) {
+            const int t = m - fdiv(m, p.rT) * p.T;
+            float4 cs[TN][2], sn[TN][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_base + j * 32 + fk * 16;
+                const int nn = n - fdiv(n, p.rD) * p.D;
+                const int jd = (nn - fdiv(nn, p.rhd) * p.hd) >> 1;
+                const float* cp = p.rope_cos + (int64_t)t * hd2 + jd;
+                const float* sp = p.rope_sin + (int64_t)t * hd2 + jd;
+                cs[j][0] = *reinterpret_cast<const float4*>(cp); cs[j][1] = *reinterpret_cast<const float4*>(cp + 4);
+                sn[j][0] = *reinterpret_cast<const float4*>(sp); sn[j][1] = *reinterpret_cast<const float4*>(sp + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_base + j * 32 + fk * 16;
+                const int sec = fdiv(n, p.rD);
+                const int nn = n - sec * p.D;
+                const float c8[8] = {cs[j][0].x, cs[j][0].y, cs[j][0].z, cs[j][0].w, cs[j][1].x, cs[j][1].y, cs[j][1].z, cs[j][1].w};
+                const float s8[8] = {sn[j][0].x, sn[j][0].y, sn[j][0].z, sn[j][0].w, sn[j][1].x, sn[j][1].y, sn[j][1].z, sn[j][1].w};
+                float o[16];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v0 = acc[i][j][2 * e], v1 = acc[i][j][2 * e + 1];
+                    o[2 * e] = fmaf(v0, c8[e], -(v1 * s8[e]));
+                    o[2 * e + 1] = fmaf(v0, s8[e], v1 * c8[e]);
+                }
+                bf16_t* dst = sec == 0 ? p.q : p.k;
+                const int64_t pl = sec == 0 ? p.q_plane : p.k_plane;
+                store8p(dst, pl, p.qkv_np, (int64_t)m * p.D + nn, o);
+                store8p(dst, pl, p.qkv_np, (int64_t)m * p.D + nn + 8, o + 8);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);        // (a slab's table loads are not hoisted over the previous slab's stores: 32 registers per slab)
+    }
+}
+
+// gated residual in the P16 layout (the arithmetic of epi_store<EPI_RESID_GATE> / gemm_bf16_wide_resid_kernel): loads of a row slab, then its stores
+template <int TM, int TN>
+__device__ __forceinline__ void wave_epilogue_resid_p16(const GemmDev& p, int g, f32x16 (&acc)[TM][TN], int row_base, int rows_end, int n_base,
+                                                        int frow, int fk) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = row_base + i * 32 + frow;
+        if (m >= rows_end) continue;
+        float* hrow = p.out32 + (int64_t)m * p.ldc32 + g * p.c_noff_group;
+        const float* grow = p.gate + (int64_t)fdiv(m, p.rT) * p.gate_ld + g * p.c_noff_group;
+        float4 hv[TN][4], gv[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32 + fk * 16;
+            if (n < p.N) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    hv[j][q] = *reinterpret_cast<const float4*>(hrow + n + 4 * q);
+                    gv[j][q] = *reinterpret_cast<const float4*>(grow + n + 4 * q);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32 + fk * 16;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 o;
+                o.x = fmaf(gv[j][q].x, acc[i][j][4 * q + 0], hv[j][q].x); o.y = fmaf(gv[j][q].y, acc[i][j][4 * q + 1], hv[j][q].y);
+                o.z = fmaf(gv[j][q].z, acc[i][j][4 * q + 2], hv[j][q].z); o.w = fmaf(gv[j][q].w, acc[i][j][4 * q + 3], hv[j][q].w);
+                *reinterpret_cast<float4*>(hrow + n + 4 * q) = o;
+            }
+        }
+    }
+}
+
+template <int V> struct PkInt { static constexpr int value = V; };
+
+#define PK_MAX_GROUPS 16
+// MAXG: capacity of the row-group table held in scalar registers (0 = one group, the rows [0, M))
+// ABL (experiments build, timing only): 1 = no DMA inside the loop, 2 = no fragment reads, 3 = no MFMA, 5 = no epilogue, 6 = 1 + 2, 7 = 2 + 3;
+// TRACE: wave 0 stamps s_memtime at every stage end (arrival, release) and tile end into p.trace (64 words per workgroup)
+template <int EPI, int MAXG, int ABL = 0, bool TRACE = false>
+__global__ void __launch_bounds__(512) gemm_bf16_pk_kernel(const GemmDev p) {
+    constexpr int SLOT = 256 * 128;               // one operand of a 64-deep stage: [256 rows][128 B], 16-B chunks XOR-swizzled by row
+    constexpr bool P16L = EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU || EPI == EPI_RESID_GATE;      // 16 consecutive output columns per lane
+    static_assert(EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU || EPI == EPI_RESID_GATE || EPI == EPI_F32, "epilogues wired for the persistent kernel");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsp[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int KT = p.K >> 6;
+    const int TS = KT * p.nseg;                   // stages per tile
+
+    // ---- the row groups in 64-row units (prefix sums, all wave-uniform).  Index min(g, ng) reads the last offset for the unused entries: 0 units.
+    int ucum[MAXG + 1], goff[MAXG + 1];
+    if constexpr (MAXG > 0) {
+        const int ng = p.ngroups;
+#pragma unroll
+        for (int g = 0; g <= MAXG; ++g) goff[g] = p.group_off[g < ng ? g : ng];
+        ucum[0] = 0;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) ucum[g + 1] = ucum[g] + ((goff[g + 1] - goff[g] + 63) >> 6);
+    } else {
+        goff[0] = 0; ucum[0] = (p.M + 63) >> 6;
+    }
+    const int U = ucum[MAXG];
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, PX = gridDim.x >> 3;
+    const int ua = U * xcd / 8;
+    const int nu = U * (xcd + 1) / 8 - ua;
+    if (nu <= 0) return;
+    const int nN = p.n_tiles;
+    const int Wx = nu * nN;
+    const int w0 = (int)((int64_t)Wx * jx / PX), wend = (int)((int64_t)Wx * (jx + 1) / PX);
+    if (w0 >= wend) return;
+    const float rnu = 1.0f / (float)nu;
+
+    // next tile of the share [w, wend): at most 4 units, inside one column tile and one row group; runs of 5..7 units are halved
+    auto next = [&](int& w, PkTile& t) {
+        if (w >= wend) { t.valid = false; return; }
+        const int n = fdiv(w, rnu);
+        const int ul = w - n * nu;
+        const int ug = ua + ul;
+        int g = 0, lo = 0, hi = p.M, ub = 0, ue = U;
+        if constexpr (MAXG > 0) {
+#pragma unroll
+            for (int i = 1; i < MAXG; ++i) g += ug >= ucum[i] ? 1 : 0;
+            lo = goff[0]; hi = goff[1]; ue = ucum[1];
+#pragma unroll
+            for (int i = 1; i < MAXG; ++i)
+                if (g == i) { lo = goff[i]; hi = goff[i + 1]; ub = ucum[i]; ue = ucum[i + 1]; }
+        }
+        int run = ue - ug;
+        if (nu - ul < run) run = nu - ul;
+        if (wend - w < run) run = wend - w;
+        const int units = run <= 4 ? run : (run >= 8 ? 4 : (run + 1) >> 1);
+        t.g = g; t.row0 = lo + 64 * (ug - ub);
+        t.rows_end = hi < t.row0 + 64 * units ? hi : t.row0 + 64 * units;
+        t.n0 = n * 256; t.im = units; t.valid = true;
+        w += units;
+    };
+    // (QKV: the launcher guarantees T % 16 == 0, Tpad % 8 == 0 and 2 D % 256 == 0 - V tiles are whole tiles and their 16-token runs stay inside a clip)
+    auto is_vt = [&](const PkTile& t) { return EPI == EPI_QKV_ROPE && t.n0 >= 2 * p.D; };
+
+    // ---- DMA cursors: A runs two stages, B one stage ahead of the multiplication; each walks the same tile sequence with its own iterator
+    PkTile aT, bT, cT;
+    int wa = w0, wb = w0, wcu = w0;
+    next(wa, aT); next(wb, bT); next(wcu, cT);
+    int asrc[4], bsrc[4];                         // element offsets from p.A / p.B (< 2^31: checked by the launcher)
+    // (the lane id goes through an empty asm wherever per-tile code starts from it: what is derived from it there - source rows,
+    //  swizzled chunks, output columns - would otherwise be hoisted out of the tile loop and held in registers across the mainloop)
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto set_a = [&](const PkTile& t) {
+        const int lo_ = opaque_lane();
+        const int rr = lo_ >> 3, cs = lo_ & 7;
+        const bool vt = is_vt(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * (wave * 4 + i) + rr;
+            const int c = cs ^ ((r >> 1) & 7);
+            int slot = t.row0 + (vt ? p16_src_row(r) : r);
+            if (slot >= t.rows_end) slot = t.row0;
+            const int arow = p.a_rows ? p.a_rows[slot] : slot;
+            asrc[i] = arow * p.lda + t.g * p.a_koff_group + c * 8;
+        }
+    };
+    auto set_b = [&](const PkTile& t) {
+        const int lo_ = opaque_lane();
+        const int rr = lo_ >> 3, cs = lo_ & 7;
+        const bool vt = is_vt(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * (wave * 4 + i) + rr;
+            const int c = cs ^ ((r >> 1) & 7);
+            int nrow = t.n0 + ((P16L && !vt) ? p16_src_row(r) : r);
+            if (nrow >= p.N) nrow = 0;
+            bsrc[i] = t.g * (int)p.b_group_stride + nrow * p.ldb + c * 8;
+        }
+    };
+    set_a(aT); set_b(bT);
+    int a_kt = 0, a_seg = 0, a_slot = 0, b_kt = 0, b_seg = 0, b_slot = 1;
+    bool in_loop = false;                         // (ablations only)
+    auto issue_a = [&](int i) {
+        if constexpr (ABL == 1 || ABL == 6) { if (in_loop) return; }       // (prologue issues only)
+        const bf16_t* ab = p.A + (a_seg == 1 ? p.a_plane : 0) + a_kt * 64;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + (unsigned)asrc[i]), (lds_ptr_t)(ldsp + a_slot * SLOT + (wave * 4 + i) * 1024), 16, 0, 0);
+    };
+    auto issue_b = [&](int i) {
+        if constexpr (ABL == 1 || ABL == 6) { if (in_loop) return; }
+        const bf16_t* bb = p.B + (b_seg == 2 ? p.b_plane : 0) + b_kt * 64;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(bb + (unsigned)bsrc[i]), (lds_ptr_t)(ldsp + b_slot * SLOT + (wave * 4 + i) * 1024), 16, 0, 0);
+    };
+    // (past the last tile the cursors keep re-issuing their last tile's stages into dead slots: the wait counts stay uniform)
+    auto adv_a = [&]() {
+        a_slot = a_slot >= 3 ? a_slot - 3 : a_slot + 2;
+        if (++a_kt == KT) {
+            a_kt = 0;
+            if (++a_seg == p.nseg) {
+                a_seg = 0;
+                if (aT.valid) { next(wa, aT); if (aT.valid) set_a(aT); }
+            }
+        }
+    };
+    auto adv_b = [&]() {
+        b_slot = b_slot >= 3 ? b_slot - 3 : b_slot + 2;
+        if (++b_kt == KT) {
+            b_kt = 0;
+            if (++b_seg == p.nseg) {
+                b_seg = 0;
+                if (bT.valid) { next(wb, bT); if (bT.valid) set_b(bT); }
+            }
+        }
+    };
+
+    f32x16 acc[4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    // prologue: A0 B0 A1, stage 0 landed everywhere
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(i);
+    adv_a();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_b(i);
+    adv_b();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_a(i);
+    adv_a();
+    wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    in_loop = true;
+    unsigned long long* trp = nullptr;            // (TRACE) this workgroup's 64 stamps: [0] start, then per stage (arrive, release), tile ends interleaved as they come
+    int trn = 0;
+    auto stamp = [&]() {
+        if constexpr (TRACE) {
+            if (trp && trn < 64 && wave == 0) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) trp[trn] = t;
+                ++trn;
+            }
+        }
+    };
+    if constexpr (TRACE) { if (p.trace) trp = p.trace + (size_t)blockIdx.x * 64; }
+    stamp();
+
+    bf16x8 fa[2][4], fb[2][2];
+    int cA = 0, cB = 1;                           // ring slots of the stage being multiplied
+    int loff[4];                                  // lane part of a fragment's LDS address per 16-deep k-step: row frow, chunk (2 ks + fk) ^ swizzle(frow)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) loff[ks] = frow * 128 + (((ks * 2 + fk) ^ ((frow >> 1) & 7)) << 4);
+    // one tile: im 32-row MFMA blocks per wave row (wave-uniform branches around the blocks a short tile does not have),
+    // VT = exchanged MFMA operand roles (V third of QKV)
+    auto run_tile = [&](auto VTc, const int im) {
+        constexpr bool VT = decltype(VTc)::value != 0;
+        // fragment addresses = (slot base + the wave's row block: uniform) + the lane's swizzled offset of the k-step (loff) + i * 4096 (immediate)
+        const int abase = wr * 32 * im * 128, bbase = wc * 64 * 128;
+        auto fload = [&](int sA, int sB, int ks, int buf) {
+            if constexpr (ABL == 2 || ABL == 6 || ABL == 7) { if (in_loop) return; }
+            const unsigned char* Ab = ldsp + (sA * SLOT + abase) + loff[ks];
+            const unsigned char* Bb = ldsp + (sB * SLOT + bbase) + loff[ks];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[buf][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 4096);
+            // (all four row blocks whatever im: an unconditional definition keeps the fragment registers dead across the epilogue; the
+            //  addresses of blocks a short tile does not have stay inside the slot)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 4096);
+        };
+        auto mfma2 = [&](int buf, int i) {
+            if constexpr (ABL == 3 || ABL == 7) {
+                acc[i][0][0] += (float)fb[buf][0][0] * (float)fa[buf][i][1];
+                acc[i][1][0] += (float)fb[buf][1][2] * (float)fa[buf][i][3];
+                return;
+            }
+            if constexpr (VT) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i], fb[buf][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i], fb[buf][1], acc[i][1], 0, 0, 0);
+            } else {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][0], fa[buf][i], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[buf][1], fa[buf][i], acc[i][1], 0, 0, 0);
+            }
+        };
+        fload(cA, cB, 0, 0);
+        for (int t = 0; t < TS; ++t) {
+            const int nA = cA >= 3 ? cA - 3 : cA + 2, nB = cB >= 3 ? cB - 3 : cB + 2;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cur = ks & 1;
+                if (ks == 3) {
+                    // stage boundary: my reads of this stage are in registers; after the barrier the next stage is here for everyone
+                    // and this stage's two slots may be refilled (the DMA issues of the next stage's first two k-steps)
+                    stamp();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    wait_vmcnt<4>();
+                    __builtin_amdgcn_s_barrier();
+                    stamp();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < im) {
+                        mfma2(cur, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (i == 0) {
+                        // next k-step's fragments, requested two MFMAs into this k-step's batch (they fly under the rest of it); the
+                        // first k-step of the next TILE is requested after the epilogue instead (its registers are the epilogue's)
+                        if (ks < 3) fload(cA, cB, ks + 1, cur ^ 1);
+                        else if (t + 1 < TS) fload(nA, nB, 0, cur ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (ks == 0) { issue_b(i); __builtin_amdgcn_sched_barrier(0); }
+                    if (ks == 1) { issue_a(i); __builtin_amdgcn_sched_barrier(0); }
+                }
+                if (ks == 0) adv_b();
+                if (ks == 1) adv_a();
+            }
+            cA = nA; cB = nB;
+        }
+    };
+
+    while (cT.valid) {
+        const bool vt = is_vt(cT);
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            if (vt) run_tile(PkInt<1>(), cT.im);
+            else run_tile(PkInt<0>(), cT.im);
+        } else {
+            run_tile(PkInt<0>(), cT.im);
+        }
+        // ---- epilogue straight from the accumulators; rows of the blocks a wave row does not own (IM < 4) are masked by its row end
+        const int row_base = cT.row0 + wr * 32 * cT.im;
+        int rows_end_w = row_base + 32 * cT.im;
+        if (cT.rows_end < rows_end_w) rows_end_w = cT.rows_end;
+        const int n_base = cT.n0 + wc * 64;
+        if constexpr (ABL == 5) {
+            float sink = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sink += acc[i][0][0] + acc[i][1][9];
+            if (sink == 12345.678f) p.out32[0] = sink;
+            zero_acc();
+            next(wcu, cT);
+            continue;
+        }
+        const int le_ = opaque_lane();
+        const int frow_e = le_ & 31, fk_e = le_ >> 5;
+        if constexpr (EPI == EPI_QKV_ROPE) {
+            if (vt) wave_epilogue_vt_pk<4, 2>(p, acc, row_base, rows_end_w, n_base, frow_e, fk_e);
+            else wave_epilogue_qk_p16<4, 2>(p, acc, row_base, rows_end_w, n_base, frow_e, fk_e);
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            wave_epilogue_swiglu_p16<4, 2>(p, cT.g, acc, row_base, rows_end_w, n_base, frow_e, fk_e);
+        } else if constexpr (EPI == EPI_RESID_GATE) {
+            wave_epilogue_resid_p16<4, 2>(p, cT.g, acc, row_base, rows_end_w, n_base, frow_e, fk_e);
+        } else {
+            wave_epilogue<EPI, 4, 2>(p, cT.g, acc, row_base, rows_end_w, n_base, frow_e, fk_e);
+        }
+        stamp();
+        zero_acc();
+        next(wcu, cT);
+    }
+    wait_vmcnt<0>();                              // the cursors' dummy tail loads must have landed before the workgroup's LDS is handed on
+}
+
+static int vb_num_cus() {
+    static std::atomic<int> cached[64] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 63;
+    int n = cached[d].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        cached[d].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+template <int EPI, int MAXG>
+static void launch_pk_g(const GemmDev& d, hipStream_t st) {
+    static OnceFlags attr;
+    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(gemm_bf16_pk_kernel<EPI, MAXG>), 5 * 256 * 128);
+    const int grid = vb_num_cus() / 8 * 8;        // one workgroup per CU (160 KB of LDS each)
+    hipLaunchKernelGGL((gemm_bf16_pk_kernel<EPI, MAXG>), dim3(grid), dim3(512), 5 * 256 * 128, st, d);
+}
+template <int ABL, bool TRACE>
+static void launch_pk_x(const GemmDev& d, hipStream_t st) {
+    static OnceFlags attr;
+    vb_set_max_lds_once(attr, reinterpret_cast<const void*>(gemm_bf16_pk_kernel<EPI_F32, 0, ABL, TRACE>), 5 * 256 * 128);
+    hipLaunchKernelGGL((gemm_bf16_pk_kernel<EPI_F32, 0, ABL, TRACE>), dim3(vb_num_cus() / 8 * 8), dim3(512), 5 * 256 * 128, st, d);
+}
+// plain fp32-output GEMM on the persistent kernel (tools/gemm_pk_bench.py): VB_GEMM_PK_F32 = 1 + ablation code, 100 = traced
+static void launch_pk_f32(const GemmDev& d0, hipStream_t st, int code) {
+    GemmDev d = d0;
+    d.n_tiles = cdiv(d.N, 256);
+    switch (code) {
+        case 100: launch_pk_x<0, true>(d, st); break;
+        case 2: launch_pk_x<1, false>(d, st); break;
+        case 3: launch_pk_x<2, false>(d, st); break;
+        case 4: launch_pk_x<3, false>(d, st); break;
+        case 6: launch_pk_x<5, false>(d, st); break;
+        case 7: launch_pk_x<6, false>(d, st); break;
+        case 8: launch_pk_x<7, false>(d, st); break;
+        default: launch_pk_x<0, false>(d, st); break;
+    }
+}
+template <int EPI>
+static void launch_pk(const GemmDev& d0, hipStream_t st) {
+    GemmDev d = d0;
+    d.n_tiles = cdiv(d.N, 256);
+    if (!d.group_off) launch_pk_g<EPI, 0>(d, st);
+    else if constexpr (EPI != EPI_QKV_ROPE) {       // (QKV has no row groups)
+        if (d.ngroups <= 8) launch_pk_g<EPI, 8>(d, st);
+        else launch_pk_g<EPI, PK_MAX_GROUPS>(d, st);
+    }
+}
+
+#endif  // VB_EXPERIMENTS (persistent kernel)
+
 template <int EPI>
 static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     // 128 x 128 tiles, two workgroups per CU: tile DMA (global_load_lds) with BK = 64 x 2 stages; K % 64 = 32 (96-channel bands at 8
@@ -2242,11 +2727,24 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const bool lay = a.epi == EPI_QKV_ROPE ? (d.hd % 16 == 0 && d.D % 16 == 0 && !a.group_off && a.ngroups <= 1)
                                                : (a.ldc % 8 == 0 && a.c_noff_group % 8 == 0);
         if (lay && t88 >= P8_MIN_TILES) cfg = 89;
+#ifdef VB_EXPERIMENTS
+        // round 5: the persistent form of the same tile (gemm_bf16_pk_kernel, bit-identical again) - MEASURED NOT FASTER (profiles/r05_gemm_pk_ab.txt,
+        // DESIGN 5.0): an experiments-build opt-in (VB_GEMM_PK=1), the product keeps the per-tile launch
+        const bool pk_ok = a.epi == EPI_SWIGLU ? (!a.group_off || a.ngroups <= PK_MAX_GROUPS)
+                                               : ((d.T & 15) == 0 && (d.Tpad & 7) == 0 && !d.no_vt16 && ((2 * d.D) & 255) == 0 && a.q.np == a.vt.np);
+        if (cfg == 89 && vb_tune().gemm_pk > 0 && gz == 1 && pk_ok && (int64_t)a.M * a.lda < (1ll << 31) &&
+            (int64_t)(a.ngroups > 0 ? a.ngroups : 1) * a.b_group_stride + (int64_t)a.N * a.ldb < (1ll << 31)) cfg = 90;
+#endif
     }
     // the 192 x 192 tile with the RoPE / V-transpose epilogue needs more registers than a wave has (640 B of scratch at 256 VGPRs): QKV takes the
     // 128 x 128 tiles wherever the rules above (or VB_GEMM_TILE) say 33 - M in (2176, 2560] rows - bit-identical like every tile choice
     if (cfg == 33 && a.epi == EPI_QKV_ROPE) cfg = 0;
 #ifdef VB_EXPERIMENTS
+    if (a.epi == EPI_F32 && vb_tune().gemm_pk_f32 > 0 && a.K % 64 == 0 && !row_groups && a.ngroups <= 1 && a.conv_ci == 0 && !a.add32) {
+        launch_pk_f32(d, st, vb_tune().gemm_pk_f32);
+        VB_CHECK_LAUNCH();
+        return VB_OK;
+    }
     // 8-wave 256 x 256 kernel (variant 4): taken when the problem makes enough of its tiles to occupy a good part of the chip - it
     // moves half the bytes per flop through the L2 -> LDS feed, so it wins even at ~55 % of the CUs busy (12032 x 768: 141 tiles);
     // small problems (one 20 s clip: 18 tiles) stay on the 128 x 128 kernel.  VB_GEMM_P8 = 0 off / 1..3 force a ring shape.
@@ -2281,7 +2779,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         VB_CHECK_LAUNCH();
         return VB_OK;
     }
-    const int bm = cfg ? 64 * (cfg / 10 > 4 ? 4 : cfg / 10) : BM, bn = cfg ? 64 * (cfg % 10 > 4 ? 4 : cfg % 10) : BN;
+    const int cfgt = cfg == 90 ? 89 : cfg;           // (the persistent kernel walks the 8-wave kernel's 256 x 256 tiles; it sizes its own grid)
+    const int bm = cfgt ? 64 * (cfgt / 10 > 4 ? 4 : cfgt / 10) : BM, bn = cfgt ? 64 * (cfgt % 10 > 4 ? 4 : cfgt % 10) : BN;
     int mt = row_groups ? (cdiv(a.M, bm) + a.ngroups) : cdiv(a.M, bm);
     d.n_tiles = cdiv(a.N, bn);
     d.grp_rows = 0; d.grp_tiles = 0; d.grp_xcd = 0;
@@ -2304,12 +2803,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
 #ifdef VB_EXPERIMENTS
 #define VB_P8_LAUNCH(E) if constexpr (P8Epi<E>::ok) launch_p8<E>(d, grid, st, vb_tune().gemm_p8);
+#define VB_PK_LAUNCH(E) if constexpr (E == EPI_QKV_ROPE || E == EPI_SWIGLU) launch_pk<E>(d, st);
 #else
 #define VB_P8_LAUNCH(E)
+#define VB_PK_LAUNCH(E)
 #endif
 #define VB_GEMM_CASE(E) \
         case E: \
             if (cfg == 88) { VB_P8_LAUNCH(E) } \
+            else if (cfg == 90) { VB_PK_LAUNCH(E) } \
             else if (cfg == 89) launch_p8_product<E>(d, grid, st); \
             else if (cfg == 33) { if constexpr (E != EPI_QKV_ROPE) launch_big<E, 3, 3, 3>(d, grid, st); } \
             else if (cfg == 11) launch_big<E, 1, 1, 3>(d, grid, st); \
@@ -2332,6 +2834,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
 #undef VB_GEMM_CASE
 #undef VB_P8_LAUNCH
+#undef VB_PK_LAUNCH
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
