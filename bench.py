@@ -643,11 +643,14 @@ def main():
     # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every 7th launch of each class bracketed by
     # HIP events on the launch stream.  This is the kernel-quality figure (roofline.frac): in the timed region below two
     # sub-batches share the CUs, so a launch's event-bracketed duration includes the other stream's kernels.
-    EVERY = 7            # sampling stride: must be coprime with the launches per network evaluation (4 blocks x 6 + FinalLayer = 25 GEMM-class
-                         # launches since the routed w2 became one launch; 5 sampled the same five kernels for ever) and with the per-pass
-                         # counts of the other classes (200, 129, 18).  Bracketing EVERY launch is not an option: back-to-back event pairs
-                         # double the reading of the long conv kernels (60.8 ms against rocprofv3's 30), while a sampled launch between
-                         # un-bracketed neighbours agrees with rocprofv3 to 2 %.
+    # EXACT per-class totals (round 5): a class's launches are timed in rotating phases - launch i of class 0 (the GEMM class, ~1250 launches
+    # per pass) in the pass with pass % 7 == i % 7, launch i of the other classes (attention 200, convolutions 129, ResBlock pairs 18 per
+    # pass) in the pass with pass % 2 == i % 2 - so over PROF_PASSES = 14 passes EVERY launch of every class is timed (GEMM class twice,
+    # the others seven times) and no two neighbouring launches are ever bracketed in the same pass: back-to-back event pairs double the
+    # reading of the long conv kernels (60.8 ms against rocprofv3's 30), a bracketed launch between un-bracketed neighbours agrees with
+    # rocprofv3 to 2 %.  ms_per_pass and the algorithmic work per launch are totals over all launches, not a sample mean scaled up
+    # (rounds 3-4 timed every 7th launch: 181 GFLOP per pair launch where the true mean is 166).
+    EVERY, EVERY_OTHER, PROF_PASSES = 7, 2, 14
     table, table_sec, dominant = [], [], 0
     GROUPS = {"bf16 MFMA GEMMs of the DiT (projections, routed + band experts)": (0,), "bf16 flash attention (self + T5 cross)": (1,),
               f"VAE + vocoder convolutions in {'exact fp32 (v_mfma_f32_32x32x2_f32)' if prim == 'fp32' else 'split-bf16 (bf16x3)'}: implicit-GEMM conv1d + "
@@ -655,54 +658,70 @@ def main():
     groups, dom_group = [], None
 
     def class_rows(per, cls_meta, passes):
+        """per[cls] = totals over `passes` profiled passes: (ms of the timed launches, their flops, their bytes, all launches, timed launches);
+        every launch is timed equally often (timed / launches-per-pass times), so totals / that count are exact per-pass figures"""
         rows = []
         for cls, (ms, fl, by, n, nt) in per.items():
             if nt == 0:
                 continue
             name, bound, peak = cls_meta[cls]
+            lpp = n / passes                          # launches per pass
+            k = nt / lpp                              # how often each launch was timed
             tf, tbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e12
-            rows.append({"class": name, "bound": bound, "launches_per_pass": n / passes, "timed_launches": nt, "avg_launch_us": 1e3 * ms / nt,
-                         "ms_per_pass": ms * n / nt / passes, "algorithmic_gflop_per_launch": fl / nt / 1e9, "algorithmic_mb_per_launch": by / nt / 1e6,
+            rows.append({"class": name, "bound": bound, "launches_per_pass": lpp, "timed_launches": nt, "times_each_launch_was_timed": k,
+                         "avg_launch_us": 1e3 * ms / nt, "ms_per_pass": ms / k, "algorithmic_gflop_per_launch": fl / nt / 1e9,
+                         "algorithmic_gflop_per_pass": fl / k / 1e9, "algorithmic_mb_per_launch": by / nt / 1e6,
                          "tflops": tf, "frac_of_mfma_peak": tf / peak, "mfma_peak_tflops": peak, "algorithmic_tb_per_s": tbs,
                          "frac_of_hbm_peak": tbs / HBM_PEAK_TBS})
         return rows
+
+    def profiled_passes(w, seeds0, mask, classes, secondary=False):
+        """PROF_PASSES one-stream passes with the rotating phases; returns {cls: totals}"""
+        tot = {c: [0.0, 0.0, 0.0, 0, 0] for c in classes}
+        for i in range(PROF_PASSES):
+            L.check(lib.vb_prof_enable(mask | (EVERY << 8) | (EVERY_OTHER << 16) | ((i % EVERY) << 20) | ((i % EVERY_OTHER) << 24)), "prof")
+            run_worker(w, [seeds0 - i], secondary) if secondary else run_worker(w, [seeds0 - i])
+            torch.cuda.synchronize()
+            for c in classes:
+                r = read_prof(c)
+                for j in range(5):
+                    tot[c][j] += r[j]
+        L.check(lib.vb_prof_enable(0), "prof")
+        return {c: tuple(v) for c, v in tot.items()}
 
     if not args.no_isolated:
         w = workers[0] if S == 1 else make_worker(B, rank * B, share=workers[0]["eng"])
         run_worker(w, [-100])
         torch.cuda.synchronize()
-        L.check(lib.vb_prof_enable(0xF | (EVERY << 8)), "prof")
-        PROF_PASSES = 3          # sampled launches per class: 3 x launches / 7 (the ResBlock-pair class makes 18 launches per pass)
-        run_worker(w, [-101 - i for i in range(PROF_PASSES)])
-        torch.cuda.synchronize()
-        per = {cls: read_prof(cls) for cls in CLS}
+        per = profiled_passes(w, -101, 0xF, list(CLS))
         table = class_rows(per, CLS, PROF_PASSES)
-        L.check(lib.vb_prof_enable(0), "prof")
         # "dominant" = the kernel GROUP with the largest GPU time per pass.  The two convolution classes are one group - the VAE / vocoder
         # convolutions run on two kernel families (implicit-GEMM conv1d, fused ResBlock pairs) the way the GEMM class runs on six - and
         # with the fp32 vocoder of configs[1] that group IS the largest part of a pass; every class keeps its own row in `classes`.
+        def per_pass(c):      # (ms, flops, bytes, launches) of class c per pass, exact (every launch timed k times)
+            ms_, fl_, by_, n_, nt_ = per[c]
+            k_ = nt_ / (n_ / PROF_PASSES)
+            return ms_ / k_, fl_ / k_, by_ / k_, n_ / PROF_PASSES
         for gname, ids in GROUPS.items():
-            tms = sum(per[c][0] * per[c][3] / per[c][4] for c in ids if per[c][4]) / PROF_PASSES
-            tfl = sum(per[c][1] * per[c][3] / per[c][4] for c in ids if per[c][4]) / PROF_PASSES
-            tby = sum(per[c][2] * per[c][3] / per[c][4] for c in ids if per[c][4]) / PROF_PASSES
-            nl = sum(per[c][3] for c in ids if per[c][4]) / PROF_PASSES
+            live = [c for c in ids if per[c][4]]
+            tms = sum(per_pass(c)[0] for c in live)
+            tfl = sum(per_pass(c)[1] for c in live)
+            tby = sum(per_pass(c)[2] for c in live)
+            nl = sum(per_pass(c)[3] for c in live)
             if tms > 0:
                 groups.append({"group": gname, "classes": [CLS[c][0] for c in ids], "class_ids": list(ids), "ms_per_pass": tms, "launches_per_pass": nl,
                                "avg_launch_us": 1e3 * tms / nl, "tflops": tfl / (tms * 1e-3) / 1e12, "mfma_peak_tflops": CLS[ids[0]][2],
-                               "frac_of_mfma_peak": tfl / (tms * 1e-3) / 1e12 / CLS[ids[0]][2], "algorithmic_mb_per_launch": tby / nl / 1e6})
+                               "frac_of_mfma_peak": tfl / (tms * 1e-3) / 1e12 / CLS[ids[0]][2], "algorithmic_mb_per_launch": tby / nl / 1e6,
+                               "algorithmic_gflop_per_pass": tfl / 1e9, "ideal_ms_per_pass_at_mfma_peak": tfl / (CLS[ids[0]][2] * 1e12) * 1e3})
         dom_group = max(groups, key=lambda g: g["ms_per_pass"]) if groups else None
-        dominant = max(per, key=lambda c: per[c][0] * (per[c][3] / per[c][4]) if per[c][4] else 0.0)
+        dominant = max(per, key=lambda c: per_pass(c)[0] if per[c][4] else 0.0)
         if dom_group:
-            dominant = max(dom_group["class_ids"], key=lambda c: per[c][0] * (per[c][3] / per[c][4]) if per[c][4] else 0.0)
+            dominant = max(dom_group["class_ids"], key=lambda c: per_pass(c)[0] if per[c][4] else 0.0)
         if sec:
             # the convolution classes once more with the bf16x3 nets (classes 2 and 3 only: the DiT classes do not change)
             run_worker(w, [-110], True)
             torch.cuda.synchronize()
-            L.check(lib.vb_prof_enable(0xC | (EVERY << 8)), "prof")
-            run_worker(w, [-111 - i for i in range(PROF_PASSES)], True)
-            torch.cuda.synchronize()
-            table_sec = class_rows({cls: read_prof(cls) for cls in (2, 3)}, classes_for(sec), PROF_PASSES)
-            L.check(lib.vb_prof_enable(0), "prof")
+            table_sec = class_rows(profiled_passes(w, -131, 0xC, [2, 3], True), classes_for(sec), PROF_PASSES)
         if S > 1:
             del w
             torch.cuda.empty_cache()
@@ -879,8 +898,10 @@ def main():
                          "how": ("dominant group = largest GPU time per pass (the two convolution classes count as one group, like the six GEMM kernels "
                                  "count as one class); achieved = algorithmic flops of its launches / their durations, from the event-timed launches "
                                  "of each of its classes scaled to the class's launch count, measured in this run with every class ALONE on the GPU "
-                                 "(one stream, whole batch, every 7th launch bracketed by HIP events on the launch stream); `classes` and `groups` "
-                                 "list every class / group the same way") if iso else "timed-region launches (no isolated pass)",
+                                 "(one stream, whole batch, launches bracketed by HIP events on the launch stream in rotating phases over "
+                                 f"{PROF_PASSES} passes so that EVERY launch is timed - the GEMM class twice, the others seven times - and never "
+                                 "two neighbours in one pass: totals, not a scaled sample); `classes` and `groups` list every class / group the "
+                                 "same way") if iso else "timed-region launches (no isolated pass)",
                          "avg_launch_us": iso["avg_launch_us"] if iso else ((1e3 * ms / nt) if nt else None),
                          "traffic": traffic, "traffic_per_kernel": traffic_table,
                          "traffic_source": traffic_how if pmc_applies else
@@ -895,6 +916,17 @@ def main():
                                           "for eager launches + in-region events)"),
                          "classes": table, "groups": [{k: v for k, v in g.items() if k != "class_ids"} for g in groups]},
         }
+        if groups:
+            # the whole path against its roofs: every group's algorithmic flops per pass at the dense MFMA peak of its arithmetic (bf16 2.5 PF,
+            # f32 157.3 TF), summed, over the measured time of a pass - the number a round should move (round 4: 67.9 ms ideal / 143.4 = 0.47)
+            ideal = sum(g["ideal_ms_per_pass_at_mfma_peak"] for g in groups)
+            out["roofline"]["path_roofline"] = {
+                "ideal_ms_per_pass": ideal, "ms_per_step": 1e3 * elapsed / args.steps, "frac": ideal / (1e3 * elapsed / args.steps),
+                "algorithmic_tflop_per_pass": sum(g["algorithmic_gflop_per_pass"] for g in groups) / 1e3,
+                "per_group": [{"group": g["group"], "algorithmic_gflop_per_pass": g["algorithmic_gflop_per_pass"], "peak_tflops": g["mfma_peak_tflops"],
+                               "ideal_ms": g["ideal_ms_per_pass_at_mfma_peak"], "measured_ms_alone": g["ms_per_pass"]} for g in groups],
+                "how": "sum over kernel groups of (algorithmic flops per pass / dense MFMA peak of the group's arithmetic) / ms_per_step; flops = the "
+                       "library's per-launch algorithmic counts (DESIGN.md section 4) summed over every launch of a pass"}
         if sec:
             out["split"] = {
                 "what": "the same workload and the same K passes with the VAE / vocoder on split-bf16 (bf16x3: every product as hi*hi + lo*hi + hi*lo on "

@@ -50,7 +50,9 @@ int vb_has_experiments(void);
 /* HIP-event timing of one kernel class inside a region (bench.py roofline): bit 0 = bf16 GEMM,
  * bit 1 = attention, bit 2 = conv1d, bit 3 = fused ResBlock pair.  Events are recorded on the launch stream around every launch of
  * the enabled classes; vb_prof_read synchronises the device and sums the elapsed times.
- * Bits 8..15 of class_mask = sampling period n (time every n-th launch of a class per host thread; 0/1 = every launch).
+ * Bits 8..15 of class_mask = sampling period n of class 0 (time every n-th launch per host thread; 0/1 = every launch), bits 16..19 = the period of
+ * classes 1..3 (0 = the same n), bits 20..23 / 24..27 = which launch of a period is timed (class 0 / the others): walking the phases over as many
+ * regions times every launch exactly once per cycle without bracketing neighbouring launches.
  * vb_prof_read: ms_sum, flops and bytes (algorithmic work of those launches) cover the `timed` launches only; `launches` counts all launches of the class. */
 /* Tuning / A-B knobs (environment variables, read once per process; a tool or test that changes one at run time calls this
  * afterwards).  Not needed by a product caller.  Kernel selection, results bit-identical: VB_GEMM_TILE (22|33|24|42|11|21),
@@ -224,7 +226,8 @@ int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, 
 
 /* Long-form generation (BASELINE configs[4]; build-defined, the reference stops at max_len = 1500 latent tokens: vocal2music_moe.py:421).
  * vb_crossfade_windows: window results parts [nw*B][C][n] (row = w*B + b; windows of equal length n starting at starts[w], a HOST array,
- * covering [0, T) with overlaps) -> out [B][C][T], linear cross-fade over every overlap, weights normalised to one.
+ * covering [0, T) with overlaps) -> out [B][C][T], linear cross-fade over every overlap, weights normalised to one (ramp weights
+ * (u + 1) / (ov + 1) in fp32: equal to torch.linspace(0, 1, ov + 2)[1:-1] up to fp32 rounding of the ramp, ~1 ulp, not bit for bit).
  * vb_hifigan_forward_chunked: HifiGAN.spec2wav over a long mel in chunks of `chunk` frames with `halo` frames of context on both sides -
  * identical to whole-clip vocoding when halo >= the generator's receptive field; scratch_in >= B*in_ch*(chunk + 2*halo) floats,
  * scratch_out >= B*out_ch*(chunk + 2*halo)*hop floats, ws = vb_net_workspace_bytes(ctx, VB_NET_VOCODER, B, chunk + 2*halo). */

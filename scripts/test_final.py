@@ -93,13 +93,18 @@ def initialize_model(args, device, rank=0):
     model = instantiate_from_config(config.model)
     sd = None
     if rank == 0:           # rank 0 reads (or draws) the checkpoint; the other ranks receive it (one flat broadcast, bitwise checked)
-        if args.ckpt:
-            sd = torch.load(args.ckpt, map_location="cpu")["state_dict"]
-        else:       # random-init checkpoint of the configured architecture
+        def load():
+            if args.ckpt:
+                return torch.load(args.ckpt, map_location="cpu")["state_dict"]
+            # random-init checkpoint of the configured architecture
             dcfg = model.model.diffusion_model.cfg
-            sd = {"model.diffusion_model." + k: v for k, v in synth.make_state_dict(synth.dit_shapes(dcfg), args.seed).items()}
-            sd.update({"first_stage_model." + k: v for k, v in
-                       synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), args.seed + 1).items()})
+            d = {"model.diffusion_model." + k: v for k, v in synth.make_state_dict(synth.dit_shapes(dcfg), args.seed).items()}
+            d.update({"first_stage_model." + k: v for k, v in
+                      synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), args.seed + 1).items()})
+            return d
+        sd = vdist.rank0_guarded(load, "checkpoint")
+    else:
+        vdist.rank0_guarded(None, "checkpoint")
     sd, info = vdist.broadcast_state(sd, 0, device)
     if info["bytes"]:
         print(f"[rank {rank}] model weights by broadcast: {info['bytes'] / 1e6:.0f} MB in {info['ms']:.1f} ms over {info['backend']}, "
@@ -114,18 +119,17 @@ def make_vocoder(args, device, tmp_dir, rank=0):
     ranks the config and the `model_gen` weights of rank 0 travel by broadcast and the wrapper is built from them."""
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    voc = None
-    if rank == 0:
+    def load():
         if args.vocoder_ckpt:
-            voc = HifiGAN(vocoder_ckpt=args.vocoder_ckpt, device=device, precision=args.vocoder_precision)
-        else:
-            import yaml
-            hcfg = synth.HifiGanConfig()
-            os.makedirs(tmp_dir, exist_ok=True)
-            yaml.safe_dump(hcfg.as_hparams(), open(os.path.join(tmp_dir, "config.yaml"), "w"))
-            torch.save({"state_dict": {"model_gen": synth.make_state_dict(synth.hifigan_shapes(hcfg), args.seed + 2)}},
-                       os.path.join(tmp_dir, "model_ckpt_steps_0.ckpt"))
-            voc = HifiGAN(vocoder_ckpt=tmp_dir, device=device, precision=args.vocoder_precision)
+            return HifiGAN(vocoder_ckpt=args.vocoder_ckpt, device=device, precision=args.vocoder_precision)
+        import yaml
+        hcfg = synth.HifiGanConfig()
+        os.makedirs(tmp_dir, exist_ok=True)
+        yaml.safe_dump(hcfg.as_hparams(), open(os.path.join(tmp_dir, "config.yaml"), "w"))
+        torch.save({"state_dict": {"model_gen": synth.make_state_dict(synth.hifigan_shapes(hcfg), args.seed + 2)}},
+                   os.path.join(tmp_dir, "model_ckpt_steps_0.ckpt"))
+        return HifiGAN(vocoder_ckpt=tmp_dir, device=device, precision=args.vocoder_precision)
+    voc = vdist.rank0_guarded(load if rank == 0 else None, "load the vocoder")      # (a failure on rank 0 ends every rank, not a hang)
     if not multi:
         return voc
     box = [dict(voc.config) if rank == 0 else None]

@@ -32,11 +32,27 @@ def _worker(rank, world, port, out_dir):
     sds = [synth.make_state_dict(s, 11 + i) for i, s in enumerate(shapes)] if rank == 0 else None
     if rank == 0:
         sds[1]["steps"] = torch.tensor([7, 9], dtype=torch.int64)      # a non-fp32 entry rides in its own flat buffer
+        sds[1]["global_step"] = 1234                                    # python scalars / strings travel in the object broadcast
+        sds[1]["tag"] = "ema"
     got, info = vdist.broadcast_state(sds, 0, torch.device("cpu"))
     ref = [synth.make_state_dict(s, 11 + i) for i, s in enumerate(shapes)]
     ok = all(torch.equal(got[i][k], ref[i][k]) for i in range(2) for k in ref[i])
     ok = ok and info["checked"] and info["buffers"] == 2 and torch.equal(got[1]["steps"], torch.tensor([7, 9]))
+    ok = ok and got[1]["global_step"] == 1234 and got[1]["tag"] == "ema" and set(got[1]) == set(ref[1]) | {"steps", "global_step", "tag"}
     ok = ok and vdist.shard_indices(5, rank, world) == ([0, 2, 4] if rank == 0 else [1, 3])
+    # rank 0's loader: its result on rank 0, None elsewhere; a failure reaches EVERY rank as an exception before any data collective
+    r0 = vdist.rank0_guarded((lambda: 41 + 1) if rank == 0 else None, "load")
+    ok = ok and r0 == (42 if rank == 0 else None)
+
+    def boom():
+        raise FileNotFoundError("no such checkpoint")
+    try:
+        vdist.rank0_guarded(boom if rank == 0 else None, "load the checkpoint")
+        ok = False
+    except FileNotFoundError:
+        ok = ok and rank == 0
+    except RuntimeError as e:
+        ok = ok and rank != 0 and "no such checkpoint" in str(e)
     single, _ = vdist.broadcast_state({"w": torch.full((3,), 2.5)} if rank == 0 else None, 0, torch.device("cpu"))     # one dict in, one dict out
     ok = ok and torch.equal(single["w"], torch.full((3,), 2.5))
     # clip sharding: rank r owns global clips [r*B, (r+1)*B)

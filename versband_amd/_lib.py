@@ -152,7 +152,7 @@ def load(build_if_missing: bool = True):
     if not os.path.exists(LIB_PATH):
         if not build_if_missing:
             raise VersbandError(f"{LIB_PATH} is missing: run `python -m versband_amd.build`")
-        if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        if not _hipcc_available():
             raise VersbandError(f"{LIB_PATH} is missing and hipcc is not available to build it")
         build()
     elif sources_present():
@@ -165,7 +165,7 @@ def load(build_if_missing: bool = True):
             if not build_if_missing:
                 raise VersbandError(f"{LIB_PATH} is stale: built from sources {str(have)[:16]}..., the tree holds {want[:16]}... "
                                     "(run `python -m versband_amd.build`)")
-            if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            if not _hipcc_available():
                 raise VersbandError(f"{LIB_PATH} is stale and hipcc is not available to rebuild it")
             build()
     lib = C.CDLL(LIB_PATH)
@@ -175,6 +175,13 @@ def load(build_if_missing: bool = True):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _hipcc_available() -> bool:
+    """the compiler build() would run: $HIPCC as a path or as a name on PATH (build() hands it to subprocess either way)"""
+    import shutil
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return os.path.exists(hipcc) or shutil.which(hipcc) is not None
 
 
 def set_tuning(**knobs):

@@ -117,12 +117,17 @@ static double g_prof_bytes[PROF_CLASSES] = {0, 0, 0, 0};
 static long long g_prof_launches[PROF_CLASSES] = {0, 0, 0, 0};
 static thread_local size_t g_prof_open = (size_t)-1;
 static thread_local unsigned g_prof_tick[PROF_CLASSES] = {0, 0, 0, 0};
-static int g_prof_every = 1;                        // time every n-th launch of a class (per host thread)
+static thread_local unsigned g_prof_tick_gen = 0;
+static std::atomic<unsigned> g_prof_gen{1};         // bumped by vb_prof_enable: every host thread restarts its launch counters
+static int g_prof_every[PROF_CLASSES] = {1, 1, 1, 1};   // time every n-th launch of a class (per host thread) ...
+static int g_prof_phase[PROF_CLASSES] = {0, 0, 0, 0};   // ... the one with launch index % n == phase
 static std::mutex g_prof_mu;                        // several host threads (one per stream) may launch concurrently
 void prof_start(int cls, double flops, double bytes, hipStream_t st) {
     g_prof_open = (size_t)-1;
     if (!(g_prof_mask & (1 << cls))) return;
-    const bool sampled = (g_prof_tick[cls]++ % (unsigned)g_prof_every) == 0;
+    const unsigned gen = g_prof_gen.load(std::memory_order_relaxed);
+    if (g_prof_tick_gen != gen) { g_prof_tick_gen = gen; for (unsigned& t : g_prof_tick) t = 0; }
+    const bool sampled = (int)(g_prof_tick[cls]++ % (unsigned)g_prof_every[cls]) == g_prof_phase[cls];
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_launches[cls] += 1;
     if (!sampled || g_prof_next + 2 > g_prof_ev.size()) return;      // counted, not timed
@@ -767,7 +772,16 @@ int vb_prof_enable(int class_mask) {
         for (auto& e : g_prof_ev) VB_HIP(hipEventCreate(&e));
     }
     g_prof_mask = class_mask & 0xff;
-    g_prof_every = ((class_mask >> 8) & 0xff) > 0 ? ((class_mask >> 8) & 0xff) : 1;     // bits 8..15: sampling period
+    // bits 8..15: sampling period n of class 0 (the GEMM class: ~1250 launches per pass); bits 16..19: period of the other classes (0 = the same n);
+    // bits 20..23 / 24..27: the phase of class 0 / of the others - a caller that walks all phases over as many passes times EVERY launch exactly
+    // once per cycle without ever bracketing two neighbouring launches (back-to-back event pairs read long kernels twice as long)
+    const int e0 = ((class_mask >> 8) & 0xff) > 0 ? ((class_mask >> 8) & 0xff) : 1;
+    const int e1 = ((class_mask >> 16) & 0xf) > 0 ? ((class_mask >> 16) & 0xf) : e0;
+    for (int i = 0; i < PROF_CLASSES; ++i) {
+        g_prof_every[i] = i == 0 ? e0 : e1;
+        g_prof_phase[i] = ((class_mask >> (i == 0 ? 20 : 24)) & 0xf) % g_prof_every[i];
+    }
+    g_prof_gen.fetch_add(1, std::memory_order_relaxed);
     g_prof_next = 0;
     g_prof_recs.clear();
     for (int i = 0; i < PROF_CLASSES; ++i) { g_prof_flops[i] = 0; g_prof_bytes[i] = 0; g_prof_launches[i] = 0; }
@@ -1121,6 +1135,7 @@ int vb_hifigan_forward(vb_ctx* ctx, const float* mel, int B, int T, float* wav, 
     return net_run(ctx, VB_NET_VOCODER, mel, B, T, wav, ws, (hipStream_t)stream);
 }
 int vb_crossfade_windows(const float* parts, const int32_t* starts, int nw, int B, int C, int n, int T, float* out, void* stream) {
+    if (!parts || !starts || !out || nw < 1 || B < 1 || C < 1 || n < 1 || T < 1) VB_FAIL(VB_E_INVALID, "crossfade_windows: null pointer or nw/B/C/n/T < 1");
     return launch_crossfade_windows(parts, starts, nw, B, C, n, T, out, (hipStream_t)stream);
 }
 int vb_hifigan_forward_chunked(vb_ctx* ctx, const float* mel, int B, int T, int chunk, int halo, float* wav, void* ws, float* scratch_in,
@@ -1215,6 +1230,7 @@ int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int 
 }
 int vb_respair_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C, int T, int k, int dil,
                    float slope, float alpha, float beta, float* out, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !out || B < 1 || T < 1) VB_FAIL(VB_E_INVALID, "respair_f32: null pointer or B/T < 1");
     RespairF32Args a;
     a.x = x; a.out = out; a.B = B; a.C = C; a.T = T; a.k = k; a.dil = dil; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2;
     a.slope = slope; a.alpha = alpha; a.beta = beta;

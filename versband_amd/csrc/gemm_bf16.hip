@@ -1373,7 +1373,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
     }
 }
 
-// ---- variant 4: 256 x 256 tiles, 8 waves.  Round 2 measured it slower inside the DiT (quad-layout epilogues) and
+// ---- variant 4: 256 x 256 tiles, 8 waves.  Round 2 measured it slower inside the DiT (quad-layout epilogues, docs/history.md, round 2) and
 // kept it in the experiments build; with the P16 epilogues of round 3 it wins on the two wide projections (round 4, same box:
 // QKV + RoPE 65.3 -> 60.7 us, whole two-stream run +3.2 %, two clips 56.8 -> 51.8 ms) and the product library instantiates exactly those
 // two forms (software-pipelined schedule, BK 32 x 5 stages, P16 layout: launch_p8_product).  The other schedules / ring shapes /
@@ -1594,7 +1594,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_p8_kernel(const GemmDev p) {
         }
         if constexpr (STG == 2) {
             // round 3 (prepared, NOT yet measured): the P16 epilogues of the 4-wave kernels on the 256 x 256 tile - the quad-layout epilogue
-            // was what this kernel lost on in round 2 (DESIGN 5.0 "open", item 4); the V third keeps the row-per-lane stores
+            // was what this kernel lost on in round 2 (docs/history.md, round 3 open items); the V third keeps the row-per-lane stores
             static_assert(EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU, "P16 epilogues exist for QKV + RoPE and SwiGLU");
             if constexpr (EPI == EPI_QKV_ROPE) wave_epilogue_qkv_p16<4, 2>(p, acc, row0 + wr * 128, rows_end, n0 + wc * 64, frow, fk);
             else wave_epilogue_swiglu_p16<4, 2>(p, g, acc, row0 + wr * 128, rows_end, n0 + wc * 64, frow, fk);

@@ -8,6 +8,7 @@ broadcast ("RCCL broadcast of weights over xGMI only"); nothing is exchanged per
     init(rank, world, device)                 process group: "nccl" (= RCCL on ROCm) one rank per GPU; "gloo" on CPU or when all ranks of
                                               a functional test share one device (VB_ONE_DEVICE / VB_BENCH_ONE_DEVICE)
     shard_indices(n_items, rank, world)       the items rank r generates (rank::world, DistributedSampler(shuffle=False) order)
+    rank0_guarded(fn, what)                   rank 0 runs a loader, every rank learns whether it worked before the data collectives start
     broadcast_state(state, src, device)       state dict(s) from rank `src` to every rank: tensors are packed per dtype into flat
                                               buffers (one broadcast each - the fp32 checkpoints of this path make ONE), rebuilt as views;
                                               returns (state, info) with the bytes moved, the time and a checksum comparison across ranks
@@ -50,6 +51,29 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(n_items))[rank::world]
 
 
+def rank0_guarded(fn, what: str = "load"):
+    """Run fn() on rank 0 only and tell every rank whether it worked BEFORE the data collectives: a checkpoint that fails to load on
+    rank 0 would otherwise leave the other ranks blocked in the broadcast until the process-group timeout.  Rank 0 passes the loader and
+    gets its result; the other ranks pass None and get None; on failure every rank raises (rank 0 re-raises the original error)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not multi:
+        return fn() if fn is not None else None
+    result, err = None, None
+    if dist.get_rank() == 0:
+        try:
+            result = fn()
+        except BaseException as e:          # noqa: BLE001 - reported to the other ranks, then re-raised here
+            err = e
+    box = [None if err is None else f"{type(err).__name__}: {err}"]
+    dist.broadcast_object_list(box, src=0)
+    if box[0] is not None:
+        if err is not None:
+            raise err
+        raise RuntimeError(f"rank 0 failed to {what}: {box[0]}")
+    return result
+
+
 def broadcast_state(state: Union[State, Sequence[State]], src: int = 0, device: torch.device = torch.device("cpu"),
                     check: bool = True) -> Tuple[Union[State, List[State]], dict]:
     """Every rank returns rank `src`'s tensors, bit for bit.  Ranks other than `src` may pass None / empty dicts: names, shapes and
@@ -66,13 +90,15 @@ def broadcast_state(state: Union[State, Sequence[State]], src: int = 0, device: 
     info["backend"] = dist.get_backend()
     # names, shapes, dtypes - and whether rank src passed one dict or a list of them (the other ranks pass None)
     meta = [[(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items() if torch.is_tensor(v)] for sd in states] if rank == src else None
-    box = [(single, meta)]
+    # entries that are not tensors (python scalars / strings a checkpoint may carry) travel inside the same object broadcast
+    extra = [{k: v for k, v in sd.items() if not torch.is_tensor(v)} for sd in states] if rank == src else None
+    box = [(single, meta, extra)]
     dist.broadcast_object_list(box, src=src)
-    single, meta = box[0]
+    single, meta, extra = box[0]
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    out: List[State] = [dict() for _ in meta]
+    out: List[State] = [dict(e) for e in extra]
     by_dtype: Dict[str, List[Tuple[int, str, tuple]]] = {}
     for i, lst in enumerate(meta):
         for k, shp, dt in lst:
@@ -112,5 +138,6 @@ def broadcast_state(state: Union[State, Sequence[State]], src: int = 0, device: 
         if not all(torch.equal(g, gathered[src]) for g in gathered):
             raise RuntimeError("broadcast_state: a rank holds different weights than rank %d after the broadcast" % src)
         info["checked"] = True
-    # non-tensor entries (python scalars in a checkpoint) ride in the object broadcast of rank src's dict - the path's checkpoints hold none
+    # (the returned tensors are views of the flat per-dtype buffers: a caller that keeps only some of them keeps the whole buffer alive -
+    #  load_state_dict / the engines' packers copy what they need, after which the dicts can be dropped)
     return (out[0] if single else out), info

@@ -635,7 +635,10 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
                 last = m == len(rd) - 1
                 dst = xs if last else nb.buf(ch, tm)
                 al, be = (1.0 / nk, 0.0 if j == 0 else 1.0) if last else (1.0, 0.0)
-                fuse = (ch in fuse_pairs and (rk - 1) * d <= 64) if precision == "split" else (ch in fp32_pairs and (rk - 1) * d <= 60 and rk <= 17)
+                # (fp32 pair kernel: 16-byte window DMA needs T % 4 == 0 - guaranteed for every mel length, chunked runs included, when the
+                #  stage's length multiplier is a multiple of 4; other stages keep the two unfused launches)
+                fuse = (ch in fuse_pairs and (rk - 1) * d <= 64) if precision == "split" else \
+                       (ch in fp32_pairs and (rk - 1) * d <= 60 and rk <= 17 and tm % 4 == 0)
                 if hp["resblock"] == "1" and fuse and rk % 2 == 1:
                     # narrowest, longest stage: both convolutions of the pair in one launch, intermediate kept in LDS
                     # (measured: 645 us per pair against 2 x 600 us at 32 channels; at 64 channels the fused kernel
