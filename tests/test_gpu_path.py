@@ -291,6 +291,38 @@ def test_sampler_graph_replay_equals_eager(ctx, sds, monkeypatch):
     assert not torch.equal(outs[(5, 1)], outs[(9, 2)])
 
 
+def test_fused_glue_launches_are_bit_identical(engines, monkeypatch):
+    """Round 5: (a) the router adds every token to its bucket's count table (ping-pong tables cleared by the place kernel) instead of a
+    count launch per block; (b) FinalLayer, the CFG combination, the Euler update and the step counter's advance are one launch per step
+    (a wave holds both branches' velocities of its tokens).  Same integers, same fused multiply-adds: a whole sampler call - an odd number
+    of steps so that the ping-pong parity crosses call boundaries - must be bit-identical with either switch back on the separate launches,
+    and so must a stand-alone network evaluation with its routes."""
+    T, Lc, B = 752, 80, 3           # 4512 token rows: the two-kernel bucket form (N > 4096), ragged last 256-token block
+    eng = engines[(4, "bf16")]
+    inp = clip_batch(B, T, Lc)
+    t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]])
+    idx, dts = vm.euler_tables(4)   # 3 steps
+    t_idx = torch.full((2 * B,), 640, dtype=torch.int64)
+    outs = []
+    for knob in (None, "VB_BUCKET_COUNT_LAUNCH", "VB_EULER_LAUNCH"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        L.load().vb_tune_reload()
+        cond = eng.precompute_cond(t5, inp["midi"], inp["beats"], T)
+        z1 = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=21)
+        z2 = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=22)      # a second call: tables as the first one left them
+        v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
+        torch.cuda.synchronize()
+        outs.append((z1.clone(), z2.clone(), v.clone(), r.clone()))
+        if knob:
+            monkeypatch.delenv(knob)
+    L.load().vb_tune_reload()
+    assert torch.isfinite(outs[0][0]).all() and not torch.equal(outs[0][0], outs[0][1])
+    for k in (1, 2):
+        for j, what in enumerate(("sample seed 21", "sample seed 22", "velocity", "routes")):
+            assert torch.equal(outs[0][j], outs[k][j]), describe(f"fused glue vs separate launches (switch {k}, {what})", outs[k][j], outs[0][j])
+
+
 def test_gemm_tile_configurations_round_alike(engines, monkeypatch):
     """The launcher picks the GEMM tile shape (128x128 two-per-CU kernel, the 192x192 one-per-CU kernel, or 64x64 / 128x64 tiles
     for one or two clips) from the problem size, i.e. from the batch: both must produce bit-identical DiT outputs and routes, otherwise a clip's

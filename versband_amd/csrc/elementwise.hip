@@ -384,7 +384,7 @@ static void launch_router_v(dim3 grid, size_t lds, hipStream_t st, const RouterD
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
-                  hipStream_t st, const float* sc, int NS, int Hh) {
+                  hipStream_t st, const float* sc, int NS, int Hh, int* cnt, int cnt_G, int cnt_pairs) {
     const int Bq = B > 0 ? B : 1;
     // tokens per wave: TWO (round 3; rounds 1-2: four).  Two tokens side by side amortise the noise generator and the arg-max, keep the
     // wave's registers at half of the four-token form and put twice the waves on a SIMD: same box, 12032 tokens 23.1 -> 20.0 us, whole
@@ -404,6 +404,7 @@ int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, 
     a.cq = cq; a.Wg = Wg; a.bg = bg; a.la = la; a.la_rows = la_mod_rows; a.hl = hl; a.hl_ld = hl_ld; a.g1 = g1; a.g2 = g2; a.g3 = g3;
     a.N = N; a.T = T; a.D = D; a.E = E; a.ic = ic; a.ia = ia; a.mc = mc; a.ma = ma; a.lc_out = lc_out; a.B = Bq; a.seed = seed;
     a.clip_base = clip_base; a.nfe_base = nfe_base; a.step = step; a.block = block; a.sc = sc; a.NS = sc ? NS : 0; a.Hh = sc ? Hh : 1;
+    a.cnt = cnt; a.cnt_G = cnt_G; a.cnt_pairs = cnt_pairs;
     if (sc) {
         // folded caption gate: logits from attention scores + per-clip VW (see router_tokens)
         if (NS % 64 || NS > 1024 || Hh < 1 || Hh > 64 || (Hh & (Hh - 1))) VB_FAIL(VB_E_INVALID, "router: NS=%d heads=%d unsupported", NS, Hh);
@@ -528,7 +529,9 @@ __global__ void __launch_bounds__(BK_T) bucket_count_kernel(const int* __restric
 template <bool PAIRS>
 __global__ void __launch_bounds__(BK_T) bucket_place_kernel(const int* __restrict__ ic, const int* __restrict__ ia, int N, int E, int G,
                                                            const int* __restrict__ counts, int nblk, int* group_off, int* perm,
-                                                           int* pair_off, int* pair_pa) {
+                                                           int* pair_off, int* pair_pa, int* counts_clear) {
+    // (round 5) this block's row of the OTHER count table: the next router launch adds into it
+    if (counts_clear && threadIdx.x < G) counts_clear[blockIdx.x * G + threadIdx.x] = 0;
     __shared__ int base[BK_G];        // slot of this block's first token of every group (pair mode: caption slot)
     __shared__ int base2[BK_G];       // pair mode: acoustic slot of this block's first token of every pair
     __shared__ int wc[4][BK_G];
@@ -691,31 +694,38 @@ __global__ void __launch_bounds__(BKS_T) bucket_small_kernel(const int* __restri
         }
     }
 }
-int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off, int* pair_pa) {
+static_assert(RT_CNT_BLOCK == BK_T, "the router counts per bucket block");
+bool bucket_router_counts_ok(int N) { return N > BKS_T * BKS_CH; }
+int bucket_counts_ints(int N) { return 2 * (cdiv(N, BK_T) * BK_G + 32); }
+int* bucket_counts(int* perm, int N, int which) { return perm + 2 * (size_t)N + (size_t)which * (cdiv(N, BK_T) * BK_G + 32); }
+int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off, int* pair_pa,
+                  const int* counts_ready, int* counts_clear) {
     if (E > 16) VB_FAIL(VB_E_INVALID, "bucket: E=%d > 16", E);
     const bool pairs = pair_off != nullptr;
     if (pairs && E * E > 16) VB_FAIL(VB_E_INVALID, "bucket: pair mode needs E*E <= 16 (E=%d)", E);
     if (N <= BKS_T * BKS_CH) {
+        if (counts_ready) VB_FAIL(VB_E_INVALID, "bucket: router-side counts belong to the two-kernel form (N > %d)", BKS_T * BKS_CH);
         if (pairs) hipLaunchKernelGGL(bucket_small_kernel<true>, dim3(1), dim3(BKS_T), 0, st, ic, ia, N, E, group_off, perm, pair_off, pair_pa);
         else hipLaunchKernelGGL(bucket_small_kernel<false>, dim3(1), dim3(BKS_T), 0, st, ic, ia, N, E, group_off, perm, nullptr, nullptr);
         VB_CHECK_LAUNCH();
         return VB_OK;
     }
-    if (pairs && E * E > 16) VB_FAIL(VB_E_INVALID, "bucket: pair mode needs E*E <= 16 (E=%d)", E);
     const int G = pairs ? E * E : 2 * E;
     const int nblk = cdiv(N, BK_T);
-    int* counts = perm + 2 * (size_t)N;          // scratch tail of the perm buffer (see bucket_scratch_ints)
+    int* counts = bucket_counts(perm, N, 0);     // scratch tail of the perm buffer (see bucket_scratch_ints)
     if (pairs) {
-        hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
-        hipLaunchKernelGGL(bucket_place_kernel<true>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts, nblk, group_off, perm, pair_off, pair_pa);
+        if (!counts_ready) hipLaunchKernelGGL(bucket_count_kernel<true>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
+        hipLaunchKernelGGL(bucket_place_kernel<true>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts_ready ? counts_ready : counts, nblk, group_off,
+                           perm, pair_off, pair_pa, counts_clear);
     } else {
-        hipLaunchKernelGGL(bucket_count_kernel<false>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
-        hipLaunchKernelGGL(bucket_place_kernel<false>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts, nblk, group_off, perm, nullptr, nullptr);
+        if (!counts_ready) hipLaunchKernelGGL(bucket_count_kernel<false>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts);
+        hipLaunchKernelGGL(bucket_place_kernel<false>, dim3(nblk), dim3(BK_T), 0, st, ic, ia, N, E, G, counts_ready ? counts_ready : counts, nblk, group_off,
+                           perm, nullptr, nullptr, counts_clear);
     }
     VB_CHECK_LAUNCH();
     return VB_OK;
 }
-int bucket_scratch_ints(int N, int E) { return cdiv(N, BK_T) * BK_G + 64; }
+int bucket_scratch_ints(int N, int E) { (void)E; return bucket_counts_ints(N) + 64; }
 
 // ---------------------------------------------------------------------------
 // proj_in (Conv1d C -> D, k taps; vocal2music_moe.py:395) as a GEMM: the latent window of every token as one K-contiguous row

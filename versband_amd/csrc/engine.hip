@@ -46,6 +46,8 @@ static void tune_load() {
     t.band_epi_old = getenv("VB_BAND_EPI_OLD") != nullptr;
     t.conv_f32_old = getenv("VB_CONV_F32_OLD") != nullptr;
     t.gemm_p8_off = getenv("VB_GEMM_P8_OFF") != nullptr;
+    t.bucket_count_launch = getenv("VB_BUCKET_COUNT_LAUNCH") != nullptr;
+    t.euler_launch = getenv("VB_EULER_LAUNCH") != nullptr;
     t.conv_f32_rt_taps = getenv("VB_CONV_F32_RT_TAPS") != nullptr;
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
@@ -423,9 +425,14 @@ static int dit_precompute(vb_ctx* ctx, const float* t5, const int64_t* midi, con
 // ------------------------------------------------------------------------------------------
 // DiT: one evaluation (both CFG branches batched: rows [0,B) cond, [B,2B) uncond)
 // ------------------------------------------------------------------------------------------
+// sampler only: FinalLayer + CFG + Euler update + step advance as one launch (launch_final_layer_euler) - x is updated in place, v is not written
+struct EulerFuse { float* x; float cfg_scale; const float* dt_table; int k; int* step; int64_t* t_idx_cur; const int64_t* t_table; int n_steps; };
+static bool euler_fusable(const vb_ctx* ctx, int n_branch) {
+    return n_branch == 2 && ctx->w.final_w && final_layer_fused_ok(ctx->cfg.hidden, ctx->cfg.in_channels) && !vb_tune().final_gemm && !vb_tune().euler_launch;
+}
 static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const void* cond, const vb_noise* noise, int noise_step,
                        const int* step_ptr, int B, int nb, int T, int L, float* v_out, int32_t* route_out, void* ws, bool zero_vt,
-                       const float* pre_mod, const float* pre_hl, hipStream_t st) {
+                       const float* pre_mod, const float* pre_hl, hipStream_t st, int evals_before = -1, const EulerFuse* ef = nullptr) {
     const vb_dit_config& c = ctx->cfg;
     const vb_dit_weights& w = ctx->w;
     CondL cd = carve_cond(const_cast<void*>(cond), c, B, nb, T, L);
@@ -436,6 +443,12 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     const int64_t ND = (int64_t)N * D;
     if (T > c.max_len) VB_FAIL(VB_E_INVALID, "dit_forward: T=%d exceeds the RoPE table (max_len=%d, vocal2music_moe.py:421)", T, c.max_len);
     if (zero_vt) VB_HIP(hipMemsetAsync(s.vt, 0, (size_t)s.n_vt * np * sizeof(bf16_t), st));
+    // bucket counts as a side product of the router (round 5): two count tables in ping-pong - the router of block evaluation e adds into table
+    // e & 1, the place kernel that reads it clears table (e + 1) & 1 for the next router.  evals_before < 0: a stand-alone call clears both tables
+    // itself; the sampler clears them once per call and passes the number of block evaluations already done.
+    const bool rcnt = bucket_router_counts_ok(N) && !vb_tune().bucket_count_launch;
+    if (rcnt && evals_before < 0) VB_TRY(launch_fill_f32(reinterpret_cast<float*>(bucket_counts(s.perm, N, 0)), bucket_counts_ints(N), 0.f, st));
+    const int eval0 = evals_before < 0 ? 0 : evals_before;
 
     // ---- timestep embedding + all adaLN modulations + high-level gate logits (depend on (t, caption) only)
     // (the sampler tabulates them for all steps up front and passes this step's rows in pre_mod / pre_hl)
@@ -501,6 +514,10 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         // ---- Band-MoE (vocal2music_moe.py:117-185)
         VB_TRY(launch_rmsnorm_mod(s.h, bw.ffn_norm_w, mod + 3 * D, mod + 4 * D, MODW, N, D, T, c.norm_eps, u, st));
         const bool fold = cd.fold && bw.wqt_s && bw.bq_s;
+        // routed w2 as ONE launch over (caption, acoustic) pair buckets: bf16 mode, E*E <= 16 groups; otherwise the two grouped w2 launches
+        // (at EVERY batch size: the pair form and the two-launch form round differently - the gate weight rides in the bf16 hidden rows -
+        //  and a clip's bits must not depend on the batch it rides in)
+        const bool w2_pair = np == 1 && E * E <= 16 && H % 64 == 0 && D % 16 == 0 && vb_tune().w2_pair;
         // gates: injected Gumbel arrays (parity path) or counter-based draws generated inside the router kernel
         const float *g1 = nullptr, *g2 = nullptr, *g3 = nullptr;
         if (noise && noise->g1) {
@@ -552,13 +569,12 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
         //  so the [N,768]x[768,768] out_proj GEMM never runs - its only consumer is the 768->E gate, vocal2music_moe.py:119-141)
         VB_TRY(launch_router(cqa, fold ? cd.vw[i] : bw.wcg, bw.bcg, cd.la[i], B * T, hl + i * 2, hl_ld, g1, g2, g3, N, T, D, E, s.ic, s.ia, s.mc,
                              s.ma, nullptr, B, noise ? noise->seed : 0, noise ? noise->clip_base : 0, noise ? noise->nfe : 0, step_ptr, i, st,
-                             fold ? s.y32 : nullptr, cd.NS, c.heads));
+                             fold ? s.y32 : nullptr, cd.NS, c.heads, rcnt ? bucket_counts(s.perm, N, (eval0 + i) & 1) : nullptr,   // (not on the fused score + router path)
+                             w2_pair ? E * E : 2 * E, w2_pair ? 1 : 0));
         }
-        // routed w2 as ONE launch over (caption, acoustic) pair buckets: bf16 mode, E*E <= 16 groups; otherwise the two grouped w2 launches
-        // (at EVERY batch size: the pair form and the two-launch form round differently - the gate weight rides in the bf16 hidden rows -
-        //  and a clip's bits must not depend on the batch it rides in)
-        const bool w2_pair = np == 1 && E * E <= 16 && H % 64 == 0 && D % 16 == 0 && vb_tune().w2_pair;
-        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st, w2_pair ? s.pair_off : nullptr, s.pair_pa));
+        const bool rc = rcnt && !fused_router;
+        VB_TRY(launch_bucket(s.ic, s.ia, N, E, s.group_off, s.perm, st, w2_pair ? s.pair_off : nullptr, s.pair_pa,
+                             rc ? bucket_counts(s.perm, N, (eval0 + i) & 1) : nullptr, rc ? bucket_counts(s.perm, N, (eval0 + i + 1) & 1) : nullptr));
         if (route_out) {
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 0) * N, s.ic, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
             VB_HIP(hipMemcpyAsync(route_out + ((size_t)i * 2 + 1) * N, s.ia, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -613,7 +629,10 @@ static int dit_forward(vb_ctx* ctx, const float* x, const int64_t* t_idx, const 
     }
     // ---- FinalLayer (vocal2music_moe.py:287-291) -> v [Beff][C][T]
     const float* modf = mod_all + (size_t)c.depth * 6 * D;
-    if (w.final_w && final_layer_fused_ok(D, c.in_channels) && !vb_tune().final_gemm) {
+    if (ef) {
+        VB_TRY(launch_final_layer_euler(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, ef->x, ef->cfg_scale, ef->dt_table,
+                                        ef->k, ef->step, ef->t_idx_cur, ef->t_table, ef->n_steps, Beff, st));
+    } else if (w.final_w && final_layer_fused_ok(D, c.in_channels) && !vb_tune().final_gemm) {
         // one wave per token row: LayerNorm + modulate in registers, the 768 x 20 projection against LDS-resident weights (exact fp32)
         VB_TRY(launch_final_layer_fused(s.h, modf, modf + D, MODW, w.final_w, w.final_b, N, D, T, c.in_channels, 1e-6f, v_out, st));
     } else if (w.final_wp && c.in_channels % 4 == 0 && (int64_t)2 * N * H >= ND) {
@@ -903,12 +922,22 @@ static int sample_steps(vb_ctx* ctx, float* x, const void* cond, int B, int n_br
         }
         VB_TRY(launch_gemv_rows(s.temb_s, D, nullptr, 0, 1, w.hl_w, w.hl_b, n_steps, c.depth * 2, D, 0, s.hl_s, c.depth * 2, st));
     }
+    {
+        const int N = (int)s.n_tok;
+        if (bucket_router_counts_ok(N) && !vb_tune().bucket_count_launch)
+            VB_TRY(launch_fill_f32(reinterpret_cast<float*>(bucket_counts(s.perm, N, 0)), bucket_counts_ints(N), 0.f, st));
+    }
+    // FinalLayer, CFG combination, Euler update and the step counter's advance as ONE launch per step (round 5; VB_EULER_LAUNCH=1 keeps the three
+    // launches: same arithmetic, bit-identical)
+    const bool fuse = euler_fusable(ctx, n_branch);
     for (int k = 0; k < n_steps; ++k) {
         RoctxRange rs("euler_step");
-        VB_TRY(launch_step_ctl(s.step, s.t_idx_cur, s.t_table, n_steps, Beff, k == 0, st));
+        if (!fuse || k == 0) VB_TRY(launch_step_ctl(s.step, s.t_idx_cur, s.t_table, n_steps, Beff, k == 0, st));
+        EulerFuse ef{x, cfg_scale, s.dt_table, k, s.step, s.t_idx_cur, s.t_table, n_steps};
         VB_TRY(dit_forward(ctx, x, s.t_idx_cur, cond, noise, k, s.step, B, n_branch, T, L, s.v, nullptr, ws, false,
-                           tab ? s.mod_s + (size_t)k * Beff * MODW : nullptr, tab ? s.hl_s + (size_t)k * c.depth * 2 : nullptr, st));
-        VB_TRY(launch_euler_cfg(x, s.v, B, per, cfg_scale, s.dt_table, s.step, 0.f, n_branch == 2, st));
+                           tab ? s.mod_s + (size_t)k * Beff * MODW : nullptr, tab ? s.hl_s + (size_t)k * c.depth * 2 : nullptr, st, k * c.depth,
+                           fuse ? &ef : nullptr));
+        if (!fuse) VB_TRY(launch_euler_cfg(x, s.v, B, per, cfg_scale, s.dt_table, s.step, 0.f, n_branch == 2, st));
         if (traj) VB_HIP(hipMemcpyAsync(traj + (size_t)(k + 1) * B * per, x, (size_t)B * per * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     return VB_OK;

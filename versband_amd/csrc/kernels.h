@@ -186,12 +186,15 @@ int launch_final_layer(const float* h, const float* shift, const float* scale, i
 bool final_layer_fused_ok(int D, int C);
 int launch_final_layer_fused(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
                              int rows, int D, int T, int C, float eps, float* out, hipStream_t st);
+int launch_final_layer_euler(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                             int rows, int D, int T, int C, float eps, float* x, float cfg_scale, const float* dt_table, int k, int* step,
+                             int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, hipStream_t st);
 int launch_euler_cfg(float* x, const float* v, int B, int64_t per, float cfg_scale, const float* dt_table, const int* step,
                      float dt_val, int has_uncond, hipStream_t st);
 int launch_router(Planes cq, const float* Wg, const float* bg, const float* la, int la_mod_rows, const float* hl, int hl_ld,
                   const float* g1, const float* g2, const float* g3, int N, int T, int D, int E, int* ic, int* ia, float* mc,
                   float* ma, float* lc_out, int B, uint64_t seed, int64_t clip_base, int nfe_base, const int* step, int block,
-                  hipStream_t st, const float* sc = nullptr, int NS = 0, int Hh = 1);
+                  hipStream_t st, const float* sc = nullptr, int NS = 0, int Hh = 1, int* cnt = nullptr, int cnt_G = 0, int cnt_pairs = 0);
 // fused caption-gate scores + router (score_router.hip): bf16 token features x per-clip folded keys -> routing decisions, the
 // [N][NS] score matrix stays in LDS.  Bit-identical to launch_gemm(EPI_F32 scores) + launch_router(sc = scores).
 struct ScoreRouterArgs {
@@ -210,9 +213,14 @@ int launch_score_router(const ScoreRouterArgs& a, hipStream_t st);
 int launch_iota_div(int64_t* out, int n, int div, hipStream_t st);
 // (pair_off / pair_pa non-null, E*E <= 16: rank by (caption, acoustic) expert PAIR; both expert-group orders derive from it - see
 //  bucket_place_kernel.  pair_off [E*E + 1], pair_pa [N] = acoustic slot of the token in pair / caption slot p)
+// counts_ready (round 5): the per-256-token-block group counts were already accumulated by the router (RouterDev::cnt) - the count launch is
+// skipped; counts_clear: a second table the place kernel zeroes for the next router launch (ping-pong, see bucket_counts)
 int launch_bucket(const int* ic, const int* ia, int N, int E, int* group_off, int* perm, hipStream_t st, int* pair_off = nullptr,
-                  int* pair_pa = nullptr);
+                  int* pair_pa = nullptr, const int* counts_ready = nullptr, int* counts_clear = nullptr);
 int bucket_scratch_ints(int N, int E);   // perm buffers must hold 2N + this many ints
+bool bucket_router_counts_ok(int N);     // the launch takes the two-kernel (count + place) form whose count the router can provide
+int* bucket_counts(int* perm, int N, int which);    // count table `which` (0 / 1) in the scratch tail of the perm buffer
+int bucket_counts_ints(int N);           // ints of both tables together (to clear them once per call)
 int launch_gate_fold(Planes kc, Planes vct, const float* bq_s, const float* wcg, int Beff, int L, int Lpad, int Hh, int hd, int E,
                      float* cbias, float* vw, hipStream_t st);
 int launch_iota_mul(int* out, int n, int mul, hipStream_t st);

@@ -70,7 +70,12 @@ struct RouterDev {
     Planes cq; const float* Wg; const float* bg; const float* la; int la_rows; const float* hl; int hl_ld;
     const float* g1; const float* g2; const float* g3; int N, T, D, E; int* ic; int* ia; float* mc; float* ma; float* lc_out; int B;
     uint64_t seed; int64_t clip_base; int nfe_base; const int* step; int block; const float* sc; int NS, Hh;
+    // bucket counts as a side product (round 5): cnt[(n / RT_CNT_BLOCK) * cnt_G + group] += 1 for the token's expert pair (cnt_pairs) or its two
+    // expert groups - what bucket_count_kernel computed in a launch of its own; the table must be zero on entry (launch_bucket's place kernel
+    // clears the table of the NEXT launch).  Integer atomics: the sums do not depend on their order.
+    int* cnt; int cnt_G; int cnt_pairs;
 };
+#define RT_CNT_BLOCK 256      // = BK_T of the bucket kernels (elementwise.hip)
 // Phase B of the router for the RT_TPW tokens n0 .. of one wave: noise draws, arg-max, high-level gate.  A token needs 2E+2 "slots"
 // (E caption-gate, E acoustic-gate, 2 high-level-gate values): PP tokens are laid side by side in the wave (SPT = 64/PP lanes each), so
 // the counter-based noise generator, the index arithmetic and the arg-max loops run once per PP tokens.  logit_of(t0, tokq, sl) returns
@@ -127,6 +132,11 @@ __device__ __forceinline__ void router_phase_b(const RouterDev& a, const int n0,
         if (valid && sl == 0) {
             ic[n] = bi;
             ia[n] = ba;
+            if (a.cnt) {
+                int* row = a.cnt + (n / RT_CNT_BLOCK) * a.cnt_G;
+                if (a.cnt_pairs) atomicAdd(row + bi * E + ba, 1);
+                else { atomicAdd(row + bi, 1); atomicAdd(row + E + ba, 1); }
+            }
             const float m = fmaxf(z0, z1);
             const float e0 = expf(z0 - m), e1 = expf(z1 - m);
             const float inv = 1.f / (e0 + e1);

@@ -141,10 +141,17 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     v += mv(v, std::integral_constant<int, 0x143>());    // row_bcast 31
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
-template <int NQ>      // D = 256 * NQ
+// EUL (round 5): the CFG combination and the Euler update in the same launch (cfm1_audio.py:154-160: v = v_u + s (v_c - v_u); x += dt v) -
+// a wave takes TWO tokens of the conditional half and the same two of the unconditional half (rows m and m + rows / 2), so it holds
+// both branches' velocities of its tokens and updates x [B][C][T] in place with the arithmetic of euler_cfg_kernel (two fused
+// multiply-adds); the velocity tensor is never written.  Block 0 also advances the sampler's device-side step counter and the timestep
+// indices for the NEXT step (step_advance_kernel's work): nothing in this launch reads them.  Saves two launches per Euler step.
+struct FinalEuler { float* x; float cfg_scale; const float* dt_table; int k; int* step; int64_t* t_idx_cur; const int64_t* t_table; int n_steps, Beff; };
+template <int NQ, bool EUL = false>      // D = 256 * NQ
 __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restrict__ h, const float* __restrict__ shift,
                                                          const float* __restrict__ scale, int mod_ld, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, int rows, int T, int C, float eps, float* out) {
+                                                         const float* __restrict__ bias, int rows, int T, int C, float eps, float* out,
+                                                         const FinalEuler fe) {
     constexpr int D = 256 * NQ;
     extern __shared__ __attribute__((aligned(16))) float wl[];      // [C][D]
     for (int id = threadIdx.x * 4; id < C * D; id += 1024) *reinterpret_cast<float4*>(wl + id) = *reinterpret_cast<const float4*>(W + id);
@@ -153,19 +160,23 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
     // a wave walks FOUR rows at a time: every weight quad read from LDS serves all of them (the LDS reads, not the 240 FMAs per row, set
     // the pace) and their reduction chains interleave
     constexpr int RW = 4;
-    for (int row0 = (blockIdx.x * 4 + wave) * RW; row0 < rows; row0 += gridDim.x * 4 * RW) {
+    const int half = rows >> 1;
+    // row r of the group starting at row0: consecutive rows, or (EUL) tokens row0, row0 + 1 of the conditional half and of the unconditional half
+    auto row_of = [&](int row0, int r) { return EUL ? min(row0 + (r & 1), half - 1) + (r >> 1) * half : min(row0 + r, rows - 1); };
+    const int row_end = EUL ? half : rows, row_step = EUL ? 2 : RW;
+    for (int row0 = (blockIdx.x * 4 + wave) * row_step; row0 < row_end; row0 += gridDim.x * 4 * row_step) {
         float4 x[RW][NQ];
         int bb[RW], tt[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            const int row = min(row0 + r, rows - 1);
+            const int row = row_of(row0, r);
             const float* xr = h + (int64_t)row * D;
 #pragma unroll
             for (int i = 0; i < NQ; ++i) x[r][i] = *reinterpret_cast<const float4*>(xr + lane * 4 + 256 * i);
         }
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            const int row = min(row0 + r, rows - 1);
+            const int row = row_of(row0, r);
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NQ; ++i) s += (x[r][i].x + x[r][i].y) + (x[r][i].z + x[r][i].w);
@@ -208,9 +219,29 @@ __global__ void __launch_bounds__(256) final_layer_kernel(const float* __restric
         }
         if (lane < C) {
             const float bv = bias ? bias[lane] : 0.f;
+            if constexpr (EUL) {
+                const float dt = fe.dt_table[fe.k];
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
-                if (row0 + r < rows) out[((int64_t)bb[r] * C + lane) * T + tt[r]] = res[r] + bv;
+                for (int j = 0; j < 2; ++j)
+                    if (row0 + j < half) {
+                        const float vc = res[j] + bv, vu = res[2 + j] + bv;
+                        const float e = fmaf(fe.cfg_scale, vc - vu, vu);
+                        float* xp = fe.x + ((int64_t)bb[j] * C + lane) * T + tt[j];
+                        *xp = fmaf(dt, e, *xp);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    if (row0 + r < rows) out[((int64_t)bb[r] * C + lane) * T + tt[r]] = res[r] + bv;
+            }
+        }
+    }
+    if constexpr (EUL) {
+        if (blockIdx.x == 0 && fe.step) {
+            const int kn = fe.k + 1;
+            if (threadIdx.x == 0) *fe.step = kn;
+            const int ki = kn < fe.n_steps ? kn : fe.n_steps - 1;
+            for (int i = threadIdx.x; i < fe.Beff; i += 256) fe.t_idx_cur[i] = fe.t_table[ki];
         }
     }
 }
@@ -224,7 +255,27 @@ int launch_final_layer_fused(const float* h, const float* shift, const float* sc
     auto go = [&](auto nq) {
         constexpr int NQ = decltype(nq)::value;
         vb_set_max_lds_once(attr[NQ - 1], reinterpret_cast<const void*>(final_layer_kernel<NQ>), 96 * 1024);
-        hipLaunchKernelGGL(final_layer_kernel<NQ>, dim3(grid), dim3(256), sh, st, h, shift, scale, mod_ld, W, bias, rows, T > 0 ? T : 1, C, eps, out);
+        hipLaunchKernelGGL(final_layer_kernel<NQ>, dim3(grid), dim3(256), sh, st, h, shift, scale, mod_ld, W, bias, rows, T > 0 ? T : 1, C, eps, out, FinalEuler{});
+    };
+    if (D == 256) go(std::integral_constant<int, 1>()); else if (D == 512) go(std::integral_constant<int, 2>());
+    else if (D == 768) go(std::integral_constant<int, 3>()); else go(std::integral_constant<int, 4>());
+    VB_CHECK_LAUNCH();
+    return VB_OK;
+}
+// FinalLayer + CFG + Euler update + step advance in one launch (see FinalEuler): rows = 2 x (B T) token rows, conditional half first
+int launch_final_layer_euler(const float* h, const float* shift, const float* scale, int mod_ld, const float* W, const float* bias,
+                             int rows, int D, int T, int C, float eps, float* x, float cfg_scale, const float* dt_table, int k, int* step,
+                             int64_t* t_idx_cur, const int64_t* t_table, int n_steps, int Beff, hipStream_t st) {
+    if (!final_layer_fused_ok(D, C) || (rows & 1) || !x || !dt_table) VB_FAIL(VB_E_INVALID, "final_layer_euler: D=%d C=%d rows=%d unsupported", D, C, rows);
+    const size_t sh = (size_t)C * D * sizeof(float);
+    const int grid = min(cdiv(rows / 2, 8), 512);
+    FinalEuler fe{x, cfg_scale, dt_table, k, step, t_idx_cur, t_table, n_steps, Beff};
+    static OnceFlags attr[4];
+    auto go = [&](auto nq) {
+        constexpr int NQ = decltype(nq)::value;
+        vb_set_max_lds_once(attr[NQ - 1], reinterpret_cast<const void*>(final_layer_kernel<NQ, true>), 96 * 1024);
+        hipLaunchKernelGGL((final_layer_kernel<NQ, true>), dim3(grid), dim3(256), sh, st, h, shift, scale, mod_ld, W, bias, rows, T > 0 ? T : 1, C, eps,
+                           (float*)nullptr, fe);
     };
     if (D == 256) go(std::integral_constant<int, 1>()); else if (D == 512) go(std::integral_constant<int, 2>());
     else if (D == 768) go(std::integral_constant<int, 3>()); else go(std::integral_constant<int, 4>());

@@ -187,7 +187,7 @@ int launch_score_router(const ScoreRouterArgs& a, hipStream_t st) {
     r.cq = Planes{nullptr, 0, 1}; r.Wg = a.vw; r.bg = a.bg; r.la = a.la; r.la_rows = a.la_rows; r.hl = a.hl; r.hl_ld = a.hl_ld;
     r.g1 = a.g1; r.g2 = a.g2; r.g3 = a.g3; r.N = a.Beff * a.T; r.T = a.T; r.D = a.K; r.E = a.E; r.ic = a.ic; r.ia = a.ia; r.mc = a.mc; r.ma = a.ma;
     r.lc_out = nullptr; r.B = a.B > 0 ? a.B : 1; r.seed = a.seed; r.clip_base = a.clip_base; r.nfe_base = a.nfe_base; r.step = a.step;
-    r.block = a.block; r.sc = nullptr; r.NS = a.NS; r.Hh = a.Hh;
+    r.block = a.block; r.sc = nullptr; r.NS = a.NS; r.Hh = a.Hh; r.cnt = nullptr; r.cnt_G = 0; r.cnt_pairs = 0;
     const double n_tok = (double)a.Beff * a.T;
     ProfScope prof(0, 2.0 * n_tok * a.NS * a.K, 2.0 * (n_tok * a.K + (double)a.Beff * a.NS * a.K) + 16.0 * n_tok, st);
     const dim3 grid(d.tiles_per_clip * ((a.Beff + 7) / 8 * 8));
