@@ -58,7 +58,7 @@ static void tune_load() {
     t.conv_ablate = env_int("VB_CONV_ABLATE", 0);
     t.attn_ablate = env_int("VB_ATTN_ABLATE", 0); t.attn_variant = env_int("VB_ATTN_VARIANT", -1);
     t.score_fused = getenv("VB_SCORE_FUSED") != nullptr;
-    t.gemm_pk_f32 = env_int("VB_GEMM_PK_F32", 0); t.gemm_pk = env_int("VB_GEMM_PK", 0);
+    t.gemm_pk_f32 = env_int("VB_GEMM_PK_F32", 0); t.gemm_pk = env_int("VB_GEMM_PK", 0); t.gemm_p8_ring = env_int("VB_GEMM_P8_RING", 0);
     // round-2 A/B switches no test flips any more: the caption gate without the fold, the once-per-clip stem convolutions in exact fp32
     t.gate_unfolded = getenv("VB_GATE_UNFOLDED") != nullptr; t.stem_f32 = getenv("VB_STEM_F32") != nullptr;
 #endif

@@ -1376,7 +1376,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_bf16_big_kernel(const GemmDev p
 // ---- variant 4: 256 x 256 tiles, 8 waves.  Round 2 measured it slower inside the DiT (quad-layout epilogues, docs/history.md, round 2) and
 // kept it in the experiments build; with the P16 epilogues of round 3 it wins on the two wide projections (round 4, same box:
 // QKV + RoPE 65.3 -> 60.7 us, whole two-stream run +3.2 %, two clips 56.8 -> 51.8 ms) and the product library instantiates exactly those
-// two forms (software-pipelined schedule, BK 32 x 5 stages, P16 layout: launch_p8_product).  The other schedules / ring shapes /
+// two forms (software-pipelined schedule, P16 layout; ring shape: launch_p8_product).  The other schedules / ring shapes /
 // ablations below compile only with -DVB_EXPERIMENTS (`VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build`) ----
 // 256 x 256 tiles, 8 waves in two staggered groups ("ping-pong") ------------------------------------
 // What bounds the 4-wave kernels above is the L2 -> LDS feed (52-60 GB/s per CU whatever the ring, section 5 of DESIGN.md): at
@@ -1649,7 +1649,19 @@ static void launch_p8_v(const GemmDev& d, dim3 grid, hipStream_t st) {
 // product form (tile configuration 89): software-pipelined schedule, BK 32 x 5 stages, P16 column layout - QKV + RoPE and SwiGLU only
 template <int EPI>
 static void launch_p8_product(const GemmDev& d, dim3 grid, hipStream_t st) {
-    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU) launch_p8_v<EPI, 32, 5, 0, 0, 2>(d, grid, st);
+    // Ring shape (round 5): 64-deep stages x 2 (128 KB) instead of 32-deep x 5 (160 KB).  A DMA instruction of a 32-deep stage covers 16
+    // rows x HALF a 128-B line, and both halves of every line cross the CU's 64 B/clk fill path: tools/probe/tile_feed_probe measures 66 GB/s
+    // per CU for that pattern against 110 for full lines - less than a 256 x 256 tile's MFMAs consume at full rate (77).  Two 64-deep stages
+    // have one stage of lead instead of four, and still win: same box, whole network evaluation 1821 -> 1786 us at 8 clips, 1237 -> 1218 at 4
+    // (QKV + RoPE 64.3 -> 62.0 us, routed SwiGLU unchanged; profiles/r05_p8_ring_ab.txt).  Bit-identical (same k order).
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU) {
+#ifdef VB_EXPERIMENTS
+        if (vb_tune().gemm_p8_ring == 325 && d.K % 32 == 0) { launch_p8_v<EPI, 32, 5, 0, 0, 2>(d, grid, st); return; }       // the round-4 ring (A/B)
+        if (vb_tune().gemm_p8_ring == 324 && d.K % 32 == 0) { launch_p8_v<EPI, 32, 4, 0, 0, 2>(d, grid, st); return; }
+#endif
+        if (d.K % 64 == 0) launch_p8_v<EPI, 64, 2, 0, 0, 2>(d, grid, st);
+        else launch_p8_v<EPI, 32, 5, 0, 0, 2>(d, grid, st);
+    }
 }
 #ifdef VB_EXPERIMENTS
 #ifndef P8_DEFAULT_BKT
