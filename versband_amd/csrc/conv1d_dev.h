@@ -43,6 +43,10 @@ __device__ __forceinline__ float conv_out_value(const ConvDev& p, float acc, flo
 // positions of one channel: residual, accumulate-into and output move as 16-byte lane accesses, 8 full 128-B lines per wave
 // instruction.  Same arithmetic per element, same order: bit-identical to the direct form.
 #define CE_PITCH 36          // floats per staged channel row (32 + 4: keeps the 16-B reads aligned, spreads the rows over banks)
+// Round 5: the side loads (residual, accumulate-into, bias) of tile u+1 are requested BEFORE tile u's stores are issued.  vmcnt retires a
+// wave's memory operations in order: requested behind the stores (rounds 1-4) a tile's loads also waited out the previous tile's store
+// round trip - with every workgroup of a one-round launch in its epilogue at the same time that was ~10 % of a VAE layer
+// (tools/conv_f32_ablate.py: 756 -> 682 us without the epilogue at 1536 channels).  Same loads, same arithmetic, other issue order.
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_staged(const ConvDev& p, f32x16 (&acc)[TM][TN], int b, int n0, int co0, int n_count,
                                                      float* stage) {
@@ -55,40 +59,49 @@ __device__ __forceinline__ void conv_epilogue_staged(const ConvDev& p, f32x16 (&
     const int rr = lane >> 3, t4 = (lane & 7) * 4;           // read-back: channel row rr + 8k, positions t4 .. t4+3
     float* ob = p.out + (int64_t)b * p.out_bstride;
     const float* rb = p.res ? p.res + (int64_t)b * p.res_bstride : nullptr;
+    const bool has_old = p.beta != 0.f;
+    struct Side { float4 rv[4], ov[4]; float bv[4]; };
+    // tile u = jn * TM + i (the order the tiles are written in)
+    auto side_loads = [&](int u, Side& sd) {
+        const int jn = u / TM, i = u - jn * TM;
+        const int nb = n0 + (wn * TN + jn) * 32, cb = co0 + (wm * TM + i) * 32;
 #pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int nb = n0 + (wn * TN + jn) * 32;
+        for (int k = 0; k < 4; ++k) {
+            const int co = cb + rr + 8 * k, n = nb + t4;
+            const bool ok = co < p.Co && n < n_count;        // (n_count % 4 == 0 is a launch condition of this variant)
+            const int64_t oi = (int64_t)(ok ? co : 0) * p.T_out + (ok ? n : 0);
+            sd.rv[k] = (ok && rb) ? *reinterpret_cast<const float4*>(rb + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sd.ov[k] = (ok && has_old) ? *reinterpret_cast<const float4*>(ob + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sd.bv[k] = (ok && p.bias) ? p.bias[co] : 0.f;
+        }
+    };
+    Side sd;                             // ONE set of side values: a tile's results are computed first (they replace the staged values), then
+    side_loads(0, sd);                   // the set is refilled for the next tile, then the results are stored
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int cb = co0 + (wm * TM + i) * 32;
+    for (int u = 0; u < TM * TN; ++u) {
+        const int jn = u / TM, i = u - jn * TM;
+        const int nb = n0 + (wn * TN + jn) * 32, cb = co0 + (wm * TM + i) * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) patch[(4 * g + 8 * (r >> 2) + (r & 3)) * CE_PITCH + l31] = acc[i][jn][r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): own writes landed (wave-private patch)
-            float4 v[4], rv[4], ov[4];
-            float bv[4];
-            bool ok[4];
+        for (int r = 0; r < 16; ++r) patch[(4 * g + 8 * (r >> 2) + (r & 3)) * CE_PITCH + l31] = acc[i][jn][r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): own writes landed (wave-private patch)
+        float4 q[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int co = cb + rr + 8 * k, n = nb + t4;
-                ok[k] = co < p.Co && n < n_count;            // (n_count % 4 == 0 is a launch condition of this variant)
-                v[k] = *reinterpret_cast<const float4*>(patch + (rr + 8 * k) * CE_PITCH + t4);
-                const int64_t oi = (int64_t)(ok[k] ? co : 0) * p.T_out + (ok[k] ? n : 0);
-                rv[k] = (ok[k] && rb) ? *reinterpret_cast<const float4*>(rb + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ov[k] = (ok[k] && p.beta != 0.f) ? *reinterpret_cast<const float4*>(ob + oi) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bv[k] = (ok[k] && p.bias) ? p.bias[co] : 0.f;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // the patch is read before the next tile overwrites it
+        for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const float4*>(patch + (rr + 8 * k) * CE_PITCH + t4);
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // the patch is read before the next tile overwrites it
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!ok[k]) continue;
-                const int co = cb + rr + 8 * k, n = nb + t4;
-                const float a4[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, r4[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-                const float o4[4] = {ov[k].x, ov[k].y, ov[k].z, ov[k].w};
-                float q[4];
+        for (int k = 0; k < 4; ++k) {
+            q[k].x = conv_out_value(p, q[k].x, sd.bv[k], sd.rv[k].x, sd.ov[k].x); q[k].y = conv_out_value(p, q[k].y, sd.bv[k], sd.rv[k].y, sd.ov[k].y);
+            q[k].z = conv_out_value(p, q[k].z, sd.bv[k], sd.rv[k].z, sd.ov[k].z); q[k].w = conv_out_value(p, q[k].w, sd.bv[k], sd.rv[k].w, sd.ov[k].w);
+        }
+        if (u + 1 < TM * TN) {
+            __builtin_amdgcn_sched_barrier(0);           // (the refill stays behind the arithmetic that reads the set and in front of the stores)
+            side_loads(u + 1, sd);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q[e] = conv_out_value(p, a4[e], bv[k], r4[e], o4[e]);
-                *reinterpret_cast<float4*>(ob + (int64_t)co * p.T_out + n) = make_float4(q[0], q[1], q[2], q[3]);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int co = cb + rr + 8 * k, n = nb + t4;
+            if (co < p.Co && n < n_count) *reinterpret_cast<float4*>(ob + (int64_t)co * p.T_out + n) = q[k];
         }
     }
 }

@@ -405,7 +405,24 @@ void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream
         }
 #endif
         switch (g_pick_tile(n_count, d.Co, B, d.phases)) {
-            case 1: launch_cfg_g_taps<4, 1, 1, 3, 3>(d, n_count, B, st); break;
+            case 1:
+#ifdef VB_EXPERIMENTS
+                if (const char* e = getenv("VB_F32G_ABL")) {      // timing-only ablations of the 128 x 96 tile (the VAE's layers; runtime-tap loop)
+                    switch (atoi(e)) {
+                        case 1: launch_cfg_g<4, 1, 1, 3, false, 3, 1>(d, n_count, B, st); return;
+                        case 2: launch_cfg_g<4, 1, 1, 3, false, 3, 2>(d, n_count, B, st); return;
+                        case 4: launch_cfg_g<4, 1, 1, 3, false, 3, 4>(d, n_count, B, st); return;
+                        case 8: launch_cfg_g<4, 1, 1, 3, false, 3, 8>(d, n_count, B, st); return;
+                        case 16: launch_cfg_g<4, 1, 1, 3, false, 3, 16>(d, n_count, B, st); return;
+                        case 3: launch_cfg_g<4, 1, 1, 3, false, 3, 3>(d, n_count, B, st); return;
+                        case 7: launch_cfg_g<4, 1, 1, 3, false, 3, 7>(d, n_count, B, st); return;
+                        case 6: launch_cfg_g<4, 1, 1, 3, false, 3, 6>(d, n_count, B, st); return;
+                        case 100: launch_cfg_g_taps<2, 2, 2, 2, 3>(d, n_count, B, st); return;      // the 128 x 128 tile on this launch
+                        default: break;
+                    }
+                }
+#endif
+                launch_cfg_g_taps<4, 1, 1, 3, 3>(d, n_count, B, st); break;
             case 2: launch_cfg_g<2, 2, 1, 2, false, 4>(d, n_count, B, st); break;
             case 3: launch_cfg_g<2, 2, 1, 1, false, 3>(d, n_count, B, st); break;
             default:
