@@ -57,7 +57,9 @@ int vb_has_experiments(void);
 /* Tuning / A-B knobs (environment variables, read once per process; a tool or test that changes one at run time calls this
  * afterwards).  Not needed by a product caller.  Kernel selection, results bit-identical: VB_GEMM_TILE (22|33|24|42|11|21),
  * VB_GEMM_SMALL / VB_GEMM_SMALL_TILES (64x64 tiles below that many 128x128 tiles), VB_GEMM_VARIANT, VB_GEMM_NCHUNK, VB_GEMM_P8*,
- * VB_ROUTER_TPW (tokens per wave), VB_BAND_UNFUSED, VB_MOE_UNFUSED, VB_SCORE_FUSED, VB_CONV_CFG, VB_CONV_DIRECT_EPI, VB_NO_GRAPH.
+ * VB_ROUTER_TPW (tokens per wave), VB_BAND_UNFUSED, VB_MOE_UNFUSED, VB_SCORE_FUSED, VB_CONV_CFG, VB_CONV_DIRECT_EPI, VB_NO_GRAPH,
+ * VB_BUCKET_COUNT_LAUNCH (bucket counts by their own launch instead of the router's side counts), VB_EULER_LAUNCH (FinalLayer / Euler update /
+ * step advance as three launches per step instead of one).
  * Changing the arithmetic (same algorithm, low-order bits differ): VB_ATTN_DEFER (log2 threshold of the deferred softmax rescale,
  * default 8, 0 = exact running maximum), VB_STEM_F32, VB_GATE_UNFOLDED.  Timing-only ablations (results WRONG): VB_GEMM_ABLATE,
  * VB_CONV_ABLATE, VB_ATTN_ABLATE. */
