@@ -313,9 +313,17 @@ __global__ void __launch_bounds__(256, 3) conv1d_f32g_kernel(const ConvDev p) { 
     for (int t = 0; t < total; ++t) {
         const int ahead_all = min(total - 1, t + NSW - 2) - t;
         if (j == 0) {
-            // the chunk's window must have landed: it was issued in front of tile (t - ntaps + NSW - 1), so at most min(NSW - 2, ntaps)
-            // younger tiles may fly
-            g_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, p.ntaps), false);
+            // the chunk's window must have landed: it was issued at step t - ntaps in front of tile (t - ntaps + NSW - 1), so of the
+            // ahead_all tiles younger than tile t only those from that one on may fly: ahead_all - (NSW - 2 - ntaps) of them when the
+            // chunk has fewer taps than the ring runs ahead.  (Round 5: this read min(ahead_all, ntaps), which near the END of a 1-tap
+            // layer on the 4-stage ring - no weight tile left to issue behind the window - let the window's last piece fly: rare wrong
+            // tiles beside a second GPU process, profiles/r05_conv_tail_race.txt.)
+            const int lag = NSW - 2 - p.ntaps;
+#ifdef VB_EXPERIMENTS
+            if (p.old_tail_wait) g_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, p.ntaps), false);      // the round-4 count (tools/flake_conv.py)
+            else
+#endif
+            g_wait_tile<WPW, XPW>(ch == 0 || lag <= 0 ? ahead_all : max(ahead_all - lag, 0), false);
             if (act || xoob) { fix_x(ch); LDS_WAIT(0); }
         } else {
             // window ch + 1 was issued at this chunk's first tap, in front of tile (t - j + NSW - 1): younger than tile t while j <= NSW - 2
@@ -361,7 +369,13 @@ static void launch_cfg_g(ConvDev& d, int n_count, int B, hipStream_t st) {
     d.g_ntb = d.g_nt * B * d.phases; d.g_tbx = cdiv(d.g_ntb, 8);
     static OnceFlags once;
     vb_set_max_lds_once(once, (const void*)conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW, ABL, NT>, BYTES);
-    hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW, ABL, NT>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
+    int bytes = BYTES;
+#ifdef VB_EXPERIMENTS
+    if (const char* e = getenv("VB_F32G_LDSPAD")) bytes += atoi(e);      // unused LDS: fewer workgroups per CU (tools/flake_conv.py; <= 64 KB in all)
+    if (getenv("VB_F32G_NOSTAGE")) d.stage_epi = 0;
+    d.old_tail_wait = getenv("VB_F32G_OLDWAIT") ? 1 : 0;
+#endif
+    hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW, ABL, NT>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), bytes, st, d);
 }
 // Tile choice for wide layers (Co > 64).  Every configuration walks chunks, taps and channel pairs in the same order - the choice never
 // changes a bit of the result - so it is free to follow the launch's size: the busiest CU's load (workgroups on it x tile area) over a
@@ -369,6 +383,9 @@ static void launch_cfg_g(ConvDev& d, int n_count, int B, hipStream_t st) {
 // 128 x 128, the 1536 / 768-channel VAE layers 128 x 96 (768 workgroups = one round at three per CU); one or two clips: the VAE layers make
 // 48-96 workgroups of those tiles for 256 CUs and take 64 x 128 or 64 x 64 instead (one clip: fp32 conv class 14.6 -> 12.1 ms per pass).
 static int g_pick_tile(int n_count, int Co, int B, int phases) {
+#ifdef VB_EXPERIMENTS
+    if (const char* e = getenv("VB_F32G_PICK")) return atoi(e);       // force a tile configuration (tools/flake_hunt_vae.py)
+#endif
     struct Cand { int id, co, t; double eff; };
     static const Cand cands[4] = {{0, 128, 128, 1.00}, {1, 128, 96, 0.95}, {2, 64, 128, 0.85}, {3, 64, 64, 0.70}};
     int best = 0;
@@ -425,6 +442,10 @@ void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream
                 launch_cfg_g_taps<4, 1, 1, 3, 3>(d, n_count, B, st); break;
             case 2: launch_cfg_g<2, 2, 1, 2, false, 4>(d, n_count, B, st); break;
             case 3: launch_cfg_g<2, 2, 1, 1, false, 3>(d, n_count, B, st); break;
+#ifdef VB_EXPERIMENTS
+            case 4: launch_cfg_g<2, 2, 1, 2, false, 3>(d, n_count, B, st); break;      // (VB_F32G_PICK only) 64 x 128 on a 3-stage weight ring
+            case 5: launch_cfg_g<1, 4, 1, 2, false, 4>(d, n_count, B, st); break;      // (VB_F32G_PICK only) 32 x 256
+#endif
             default:
 #ifdef VB_EXPERIMENTS
                 if (const char* e = getenv("VB_F32G_ABL")) {      // timing-only ablations of the 128 x 128 tile (tools/conv_f32_ablate.py)

@@ -180,7 +180,10 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
     auto pre = [&](int t) {
         const int ahead_all = min(total - 1, t + NSW - 2) - t;
         if (conv == 0 && s == 0) {
-            pf_wait_tile<WPW, XPW>(ch == 0 ? ahead_all : min(ahead_all, NS), false);
+            // (the window went out NS steps ago in front of tile t - NS + NSW - 1: see conv1d_f32g.hip for the count; conv1's tiles follow
+            //  conv0's, so the end-of-sequence case - ahead_all < NSW - 2 - cannot meet a window here, the form is kept the same anyway)
+            const int lag = NSW - 2 - NS;
+            pf_wait_tile<WPW, XPW>(ch == 0 || lag <= 0 ? ahead_all : max(ahead_all - lag, 0), false);
             fix_x(ch);
             LDS_WAIT(0);
         } else {
