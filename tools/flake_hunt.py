@@ -2,7 +2,7 @@
 round 4's commit too.)  Runs every stage repeatedly on the same inputs - optionally beside a second process that keeps the GPU busy - and
 reports the first stage whose result ever differs from its first run.
 
-    python tools/flake_hunt.py [batches=4 (e.g. 1,2,3,8)] [reps=12] [load=1] [fp32|split]
+    python tools/flake_hunt.py [batches=4 (e.g. 1,2,3,8)] [reps=12] [load=1] [fp32|split] [experts=4] [DiT bf16|split]
 """
 import os
 import subprocess
@@ -20,6 +20,8 @@ BATCHES = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "4").split(","
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 LOAD = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 PREC = sys.argv[4] if len(sys.argv) > 4 else "fp32"      # VAE / vocoder arithmetic: fp32 | split
+EXPERTS = int(sys.argv[5]) if len(sys.argv) > 5 else 4     # 8 = configs[2]
+DIT_PREC = sys.argv[6] if len(sys.argv) > 6 else "bf16"    # bf16 | split (parity mode)
 if os.environ.get("FLAKE_LOAD_CHILD"):
     a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
     x = torch.randn(8, 256, 60000, device="cuda")
@@ -34,10 +36,10 @@ if LOAD:
 try:
     device = torch.device("cuda:0")
     T, Lc = 752, 80
-    dcfg, vcfg, hcfg = synth.DiTConfig(), synth.VAEConfig(), synth.HifiGanConfig()
+    dcfg, vcfg, hcfg = synth.DiTConfig(num_experts=EXPERTS), synth.VAEConfig(), synth.HifiGanConfig()
     sds = [synth.make_state_dict(s, 1234 + i) for i, s in enumerate([synth.dit_shapes(dcfg), synth.vae_decoder_shapes(vcfg), synth.hifigan_shapes(hcfg)])]
     ctx = Context(device)
-    eng = DiTEngine(ctx, dcfg, sds[0], precision="bf16")
+    eng = DiTEngine(ctx, dcfg, sds[0], precision=DIT_PREC)
     vae = build_vae_decoder(ctx, sds[1], precision=PREC)
     voc = build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=PREC)
     if LOAD:
