@@ -2223,7 +2223,24 @@ static void launch_t(const GemmDev& d, dim3 grid, hipStream_t st) {
     if (variant == 0) { hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, grid, dim3(NTHREADS), 0, st, d); return; }
     if (variant == 2 && d.K % 32 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 4>), grid, dim3(NTHREADS), 0, st, d); return; }
     if (variant == 3 && d.K % 32 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 32, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
-    if (variant == 4 && d.K % 64 == 0) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d); return; }
+    if ((variant == 4 || variant == 5) && d.K % 64 == 0) {
+        // deeper rings of the 128 x 128 tile (3 stages = 96 KB, 4 = 128 KB: one workgroup per CU) - the one-clip A/B of round 5: SLOWER, 41.6 ms per
+        // clip with either against 40.8 with the two-stage ring at two workgroups per CU (same box, two runs each, parity ok): DESIGN 5.0
+        constexpr bool p16able = EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU;
+        bool p16 = false;
+        if constexpr (EPI == EPI_QKV_ROPE) p16 = d.hd % 16 == 0 && d.D % 16 == 0 && d.N % 16 == 0 && !d.group_off && d.ngroups <= 1 && !vb_tune().qkv_p16_off;
+        if constexpr (EPI == EPI_SWIGLU) p16 = d.N % 16 == 0 && d.ldc % 8 == 0 && d.c_noff_group % 8 == 0 && !vb_tune().qkv_p16_off;
+        if constexpr (p16able) {
+            if (p16) {
+                if (variant == 4) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3, 0, true>), grid, dim3(NTHREADS), 0, st, d); }
+                else { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 4, 0, true>), grid, dim3(NTHREADS), 0, st, d); }
+                return;
+            }
+        }
+        if (variant == 4) { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 3>), grid, dim3(NTHREADS), 0, st, d); }
+        else { hipLaunchKernelGGL((gemm_bf16_glds_kernel<EPI, 64, 4>), grid, dim3(NTHREADS), 0, st, d); }
+        return;
+    }
 #endif
     if constexpr (EPI == EPI_QKV_ROPE) {
         // QKV + RoPE: 16 consecutive columns per lane (P16 layout) whenever heads and sections are 16-aligned and no grouping is involved
