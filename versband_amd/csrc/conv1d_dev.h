@@ -22,6 +22,7 @@ struct ConvDev {
     int stage_epi;           // [b][co][t] output, stride 1, T_out % 4 == 0, 16-B aligned rows: the staged (16-B lane) epilogue
 #ifdef VB_EXPERIMENTS
     int old_tail_wait;       // conv1d_f32g: the round-4 wait count in front of a chunk's first tap (A/B of the round-5 fix)
+    int x_nt;                // conv1d_f32g: window DMA with the non-temporal policy (VB_CONV_XNT)
 #endif
     int g_nt, g_nco, g_ntb, g_tbx;   // conv1d_f32g_kernel: time tiles, channel tiles, (time tile, clip, phase) units, units per XCD
 };

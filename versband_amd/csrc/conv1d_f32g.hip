@@ -127,6 +127,15 @@ __global__ void __launch_bounds__(256, 3) conv1d_f32g_kernel(const ConvDev p) { 
 #pragma unroll
         for (int i = 0; i < XPW; ++i) {
             const int ii = wave * XPW + i;
+#ifdef VB_EXPERIMENTS
+            // (VB_CONV_XNT=1: the window - read by one or two workgroups - with the non-temporal policy, so that it does not displace the weights
+            //  every workgroup re-reads from L2; A/B of round 5, profiles/r05_conv_window_nt.txt)
+            if (p.x_nt) {
+                if constexpr (UPS) __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 64), 4, 0, 2);
+                else __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 256), 16, 0, 2);
+                continue;
+            }
+#endif
             if constexpr (UPS) __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 64), 4, 0, 0);
             else __builtin_amdgcn_global_load_lds((g_glb_ptr_t)(src + xsrc[i]), (g_lds_ptr_t)(dst + ii * 256), 16, 0, 0);
         }
@@ -374,6 +383,7 @@ static void launch_cfg_g(ConvDev& d, int n_count, int B, hipStream_t st) {
     if (const char* e = getenv("VB_F32G_LDSPAD")) bytes += atoi(e);      // unused LDS: fewer workgroups per CU (tools/flake_conv.py; <= 64 KB in all)
     if (getenv("VB_F32G_NOSTAGE")) d.stage_epi = 0;
     d.old_tail_wait = getenv("VB_F32G_OLDWAIT") ? 1 : 0;
+    d.x_nt = getenv("VB_CONV_XNT") ? 1 : 0;
 #endif
     hipLaunchKernelGGL((conv1d_f32g_kernel<WM, WN, TM, TN, UPS, NSW, ABL, NT>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), bytes, st, d);
 }

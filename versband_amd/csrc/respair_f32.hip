@@ -17,6 +17,7 @@
 //   * conv2 over h, + b2 + residual x, alpha / beta accumulation into the MRF sum through the staged 16-byte epilogue.
 // Same chunk -> tap -> channel-pair accumulation order and the same epilogue arithmetic as conv1d_f32_kernel / conv1d_f32g_kernel:
 // the fused pair equals the two unfused fp32 launches bit for bit (up to the sign of a zero intermediate) - the test compares them.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "kernels.h"
@@ -56,6 +57,9 @@ struct PairF32Dev {
     const float* b1; const float* b2;
     float slope, alpha, beta;
     int staged;
+#ifdef VB_EXPERIMENTS
+    int x_nt;          // window DMA with the non-temporal policy (VB_CONV_XNT, see conv1d_f32g.hip)
+#endif
 };
 
 // one output element: the arithmetic of conv_out_value (conv1d_f32.hip) with acc_scale = 1 and no output activation
@@ -122,8 +126,12 @@ __global__ void __launch_bounds__(256) respair_f32_kernel(const PairF32Dev p) {
         const float* src = xb + (int64_t)ch * PF_GK * p.T;
         float* dst = lx + (ch & 1) * XST;
 #pragma unroll
-        for (int i = 0; i < XPW; ++i)
+        for (int i = 0; i < XPW; ++i) {
+#ifdef VB_EXPERIMENTS
+            if (p.x_nt) { __builtin_amdgcn_global_load_lds((pf_glb_ptr_t)(src + xsrc[i]), (pf_lds_ptr_t)(dst + (wave * XPW + i) * 256), 16, 0, 2); continue; }
+#endif
             __builtin_amdgcn_global_load_lds((pf_glb_ptr_t)(src + xsrc[i]), (pf_lds_ptr_t)(dst + (wave * XPW + i) * 256), 16, 0, 0);
+        }
     };
     // once per chunk, by the lanes that DMA'd the quads (after the wave's own DMA landed, in front of the publishing barrier): zeros over
     // the out-of-range quads and LeakyReLU in place (conv1d_f32g.hip: VALU instructions between a SIMD's MFMAs cost matrix-pipe time; 36 VALU
@@ -436,6 +444,9 @@ int launch_respair_f32(const RespairF32Args& a, hipStream_t st) {
     d.w1 = a.w1; d.w2 = a.w2; d.b1 = a.b1; d.b2 = a.b2; d.slope = a.slope; d.alpha = a.alpha; d.beta = a.beta;
     const int TT = (PF_T - (a.k - 1)) & ~3;
     d.staged = ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && !vb_tune().conv_direct_epi) ? 1 : 0;
+#ifdef VB_EXPERIMENTS
+    d.x_nt = getenv("VB_CONV_XNT") ? 1 : 0;
+#endif
     dim3 grid(cdiv(a.T, TT), 1, a.B);
     ProfScope prof(3, 2.0 * 2.0 * a.B * (double)a.C * a.C * a.k * (double)a.T,
                    4.0 * a.B * (double)a.C * a.T * (2.0 + (a.beta != 0.f ? 1.0 : 0.0)) + 2.0 * 4.0 * a.k * a.C * a.C, st);
