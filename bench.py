@@ -76,6 +76,77 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+LINE_MAX = 4096             # the driver reads the LAST stdout line as JSON; round 5's 21 KB line came back unparsed
+
+
+def _r(x, nd=6):
+    """round floats for the one-line summary (the side file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    return x
+
+
+def compact_line(out: dict, detail_path: str | None) -> str:
+    """The ONE stdout JSON line of the bench contract, <= LINE_MAX bytes: the contract keys, `roofline`, `cpu_baseline`, a
+    parity verdict and the second region's headline.  Everything tabular (per-class / per-group / per-kernel tables, the
+    verified clip list, device telemetry, prose) goes to `detail_path` (bench_detail.json), which the line names."""
+    rf = out.get("roofline") or {}
+    pr = rf.get("path_roofline") or {}
+    pc = out.get("parity_check")
+    cfg = out.get("config") or {}
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                         "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "baseline_config", "clips_per_gpu", "clip_seconds", "flow_steps", "precision", "experts",
+                                              "vocoder_precision", "streams_per_gpu", "parallelism", "sampler_loop") if k in cfg}
+    if pc is not None:
+        worst = None
+        cp = (pc.get("verified") or {}).get("clips_x_passes") or [pc]
+        for key in ("latent_rel_l2", "mel_l1_sampled", "mel_l2_rel"):
+            v = [c[key] for c in cp if isinstance(c.get(key), (int, float))]
+            if v:
+                worst = worst or {}
+                worst[key] = _r(max(v), 3)
+        rfp = pc.get("routing_flips") or {}
+        line["parity_check"] = {"ok": pc.get("ok"), "tol": pc.get("tol"), "worst": worst, "clips_x_passes_checked": len(cp),
+                                "routing_flips_per_block": rfp.get("per_block"), "routing_decisions_per_block": rfp.get("decisions_per_block")}
+    line["roofline"] = {"bound": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"),
+                        "unit": rf.get("unit"), "frac": _r(rf.get("frac"), 4), "traffic": _r(rf.get("traffic")),
+                        "algorithmic_bytes_per_launch": _r(rf.get("algorithmic_bytes_per_launch")), "avg_launch_us": _r(rf.get("avg_launch_us"), 5),
+                        "path_frac": _r(pr.get("frac"), 4), "path_ideal_ms": _r(pr.get("ideal_ms_per_pass"), 5),
+                        "groups": [{"group": g["group"].split(" (")[0][:48], "ms_per_pass": _r(g.get("ms_per_pass"), 4), "frac": _r(g.get("frac_of_mfma_peak"), 3)}
+                                   for g in (rf.get("groups") or [])]}
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        rfa = cb.get("reference_faithful") or {}
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 4), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": (cb.get("sample") or "")[:300], "reference_faithful": _r(rfa.get("value"), 4)}
+        if cb.get("error"):
+            line["cpu_baseline"]["error"] = str(cb["error"])[:200]
+    sp = out.get("split")
+    if sp is not None:
+        line["split"] = {"value": _r(sp.get("value")), "ms_per_step": _r(sp.get("ms_per_step")), "vocoder_precision": sp.get("vocoder_precision"),
+                         "parity_ok": (sp.get("parity_check") or {}).get("ok")}
+    rk = out.get("ranks") or {}
+    if (rk.get("world") or 1) > 1:
+        line["ranks"] = {"backend": rk.get("backend"), "weight_broadcast_ms": _r(rk.get("weight_broadcast_ms"), 4),
+                         "weight_broadcast_gbps": _r(rk.get("weight_broadcast_gbps"), 4), "per_rank_ms": [_r(x, 5) for x in (rk.get("per_rank_ms") or [])][:8],
+                         "collectives_in_timed_region": rk.get("collectives_in_timed_region")}
+    line["detail"] = detail_path
+    s = json.dumps(line, separators=(",", ":"))
+    # belt and braces: shed optional blocks before ever exceeding the limit (never the contract keys, roofline or cpu_baseline)
+    for drop in ("ranks", "split", "data"):
+        if len(s) <= LINE_MAX:
+            break
+        line.pop(drop, None)
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_MAX:
+        line["config"] = {"workload": str(cfg.get("workload"))[:200]}
+        line["roofline"].pop("groups", None)
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= LINE_MAX and "\n" not in s, len(s)
+    return s
+
+
 def _class_patterns(cls):
     """kernel-name patterns of a class id or of a group (tuple) of class ids"""
     ids = cls if isinstance(cls, (tuple, list)) else (cls,)
@@ -284,6 +355,8 @@ def parse():
     ap.add_argument("--cpu-flow-steps", type=int, default=4)
     ap.add_argument("--cpu-timeout", type=float, default=240.0)
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="side file for the per-class / per-group / per-kernel tables (the stdout line stays <= 4 KB and names this path)")
     ap.add_argument("--save-out", default=None, help="directory: every rank writes the waveforms of its last pass (clip-indexed .npy)")
     a = ap.parse_args()
     dflt = {"c2": (8, 4, 20.0, 2), "c3": (32, 8, 20.0, 2), "c5": (4, 4, 120.0, 1)}[a.workload]
@@ -937,7 +1010,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
-        print(json.dumps(out))
+        detail_path = args.detail
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)) or ".", exist_ok=True)
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:                     # a read-only checkout must not cost the line
+            log(f"could not write {detail_path}: {e}")
+            detail_path = None
+        sys.stderr.flush()
+        print(compact_line(out, detail_path), flush=True)
         if (parity is not None and parity.get("ok") is False) or (parity_sec is not None and parity_sec.get("ok") is False):
             log("PARITY CHECK FAILED")
     if rank == 0:

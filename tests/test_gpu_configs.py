@@ -258,9 +258,24 @@ def test_c5_longform_at_size(ctx):
     torch.cuda.synchronize()
     keep = plan[1][0]
     assert torch.equal(z[:, :, :keep].cpu(), z0[:, :, :keep].cpu()), describe("window interior", z[:, :, :keep], z0[:, :, :keep])
-    # inside an overlap the result is a convex combination of the two windows' latents
-    lo = torch.minimum(z0[:, :, keep:n0].cpu(), z0[:, :, keep:n0].cpu())
-    assert torch.isfinite(lo).all()
+    # inside the first overlap [1372, 1500) the result is the convex combination w * z_next + (1 - w) * z_prev of the two windows' own
+    # latents, w the linear ramp of crossfade_windows (window 1 = batch row 1 of the chunked call, so its clip key is clip_base 1)
+    s1, n1 = plan[1]
+    cond1 = eng.precompute_cond(torch.cat([inp["t5_cond"], inp["t5_uncond"]]), inp["midi"][..., 2 * s1:2 * (s1 + n1)],
+                                inp["beats"][..., 2 * s1:2 * (s1 + n1)], n1)
+    z1 = eng.sample_cfg(inp["x_latent"][:, :, s1:s1 + n1].contiguous(), cond1, idx, dts, 3.0, seed=3, clip_base=1)
+    torch.cuda.synchronize()
+    ov = n0 - keep
+    assert ov == 128
+    wgt = torch.linspace(0, 1, ov + 2, dtype=torch.float64)[1:-1]
+    zp, zn, zo = z0[:, :, keep:n0].cpu().double(), z1[:, :, :ov].cpu().double(), z[:, :, keep:n0].cpu().double()
+    expect = wgt * zn + (1.0 - wgt) * zp
+    err = ((zo - expect).abs() / expect.abs().clamp_min(1.0)).max()
+    assert float(err) <= 2e-7, f"overlap is not w * z_next + (1 - w) * z_prev: {float(err):.3e}"
+    assert bool(((zo >= torch.minimum(zp, zn) - 1e-6) & (zo <= torch.maximum(zp, zn) + 1e-6)).all())
+    # and past the overlap, up to the next one, the chunked result IS window 1's own latent
+    nxt = plan[2][0]
+    assert torch.equal(z[:, :, n0:nxt].cpu(), z1[:, :, n0 - s1:nxt - s1].cpu())
     sdv = synth.make_state_dict(synth.vae_decoder_shapes(synth.VAEConfig()), SEED + 1)
     mel = build_vae_decoder(ctx, sdv).run(z)
     assert mel.shape == (B, 80, 2 * T) and torch.isfinite(mel).all()

@@ -19,11 +19,27 @@ def _bench(args, env_extra, timeout=900):
     env = dict(os.environ)
     env.update(env_extra)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(prefix="vb_bench_"), "bench_detail.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail", detail] + args, capture_output=True, text=True, timeout=timeout,
+                       env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}"
-    return json.loads(lines[0])
+    # the driver's contract (round 5's 21 KB line came back `parsed: null`): the LAST stdout line is the one JSON object, <= 4 KB
+    out_lines = r.stdout.strip().splitlines()
+    lines = [ln for ln in out_lines if ln.startswith("{")]
+    assert len(lines) == 1 and out_lines[-1] == lines[0], f"exactly one JSON line, last on stdout, expected; got {len(lines)}"
+    assert len(lines[0]) <= 4096, len(lines[0])
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "config",
+              "roofline", "detail"):
+        assert k in line, k
+    assert line["detail"] == detail
+    full = json.load(open(detail))
+    assert abs(full["value"] - line["value"]) <= 1e-5 * full["value"] and full["n_gpus"] == line["n_gpus"]
+    assert line["config"]["workload"] == full["config"]["workload"]
+    if full.get("parity_check") is not None:
+        assert line["parity_check"]["ok"] == full["parity_check"]["ok"]
+    return full
 
 
 def test_two_ranks_one_command_match_single_process(tmp_path):

@@ -300,3 +300,107 @@ def test_entry_script_keeps_the_reference_cli(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["test_final.py"])
     d = mod.parse_args()
     assert d.scales == "1-3" and d.scale == 3.0 and d.n_samples == 1 and d.save_dir == "test" and d.num_gpus == 1 and d.sample_rate == 24000
+
+
+def test_bench_line_is_one_short_json_line():
+    """Round 5's bench line grew to 21 KB and the driver recorded `parsed: null`.  The stdout line is built by
+    bench.compact_line() from the full result dict: <= 4 KB, one `{...}` line, every contract key + `roofline` + `cpu_baseline`
+    present; the tables go to the side file it names.  Canned input: the committed round-5 result (profiles/r05_final_bench_c2.json),
+    once as is and once inflated (8 ranks, long strings) to prove the limit holds by construction."""
+    import copy
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final_bench_c2.json")))
+    assert len(json.dumps(full)) > 15000                     # the canned dict IS the oversized one
+    big = copy.deepcopy(full)
+    big["n_gpus"] = 8
+    big["ranks"].update({"world": 8, "backend": "nccl (RCCL)", "weight_broadcast_ms": 123.456789, "weight_broadcast_gbps": 45.678901,
+                         "per_rank_ms": [139.391012518] * 8})
+    big["config"]["workload"] = big["config"]["workload"] * 3
+    big["cpu_baseline"]["sample"] = big["cpu_baseline"]["sample"] * 5
+    for src in (full, big):
+        s = bench.compact_line(src, "/tmp/bench_detail.json")
+        assert len(s) <= bench.LINE_MAX == 4096 and "\n" not in s and s.startswith("{") and s.endswith("}")
+        d = json.loads(s)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "config", "parity_check", "roofline", "cpu_baseline", "detail"):
+            assert k in d, k
+        assert d["metric"] == src["metric"] and d["unit"] == "mel-s/s" and d["n_gpus"] == src["n_gpus"]
+        assert abs(d["value"] - src["value"]) <= 1e-5 * src["value"] and abs(d["ms_per_step"] - src["ms_per_step"]) <= 1e-5 * src["ms_per_step"]
+        assert "workload" in d["config"] and "model" not in d["config"]
+        rf = d["roofline"]
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "path_frac"):
+            assert k in rf, k
+        assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        cb = d["cpu_baseline"]
+        assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "mel-s/s" and cb["sample"]
+        assert d["parity_check"]["ok"] is True and d["parity_check"]["worst"]["latent_rel_l2"] < 1e-3
+    d8 = json.loads(bench.compact_line(big, None))
+    assert d8["ranks"]["backend"] == "nccl (RCCL)" and len(d8["ranks"]["per_rank_ms"]) == 8 and d8["detail"] is None
+    # a result without the optional blocks (--no-parity-check --no-cpu-baseline --no-isolated) still makes a line
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data", "config")}
+    bare["roofline"] = {"bound": "mfma", "kernel": "k", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None}
+    bare["parity_check"] = None
+    assert json.loads(bench.compact_line(bare, None))["roofline"]["frac"] == 0.5
+
+
+def _model_keys(tree, prefix=""):
+    out = set()
+    if isinstance(tree, dict):
+        for k, v in tree.items():
+            out.add(prefix + k)
+            out |= _model_keys(v, prefix + k + ".")
+    return out
+
+
+def _check_boundary_config(path):
+    """load_config -> instantiate_from_config(config.model) -> CFMSampler(model, 1000), the three calls of
+    scripts/test_final.py initialize_model (reference :137-150), then the attributes the harness reads."""
+    import warnings
+    cfg = vm.load_config(path)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = vm.instantiate_from_config(cfg.model)
+    assert type(m).__name__ == "CFM"
+    assert m.num_timesteps == 1000 and (m.mel_dim, m.mel_length, m.channels) == (20, 750, 0)
+    assert m.first_stage_model.embed_dim == 20 and m.first_stage_model.ddconfig["ch_mult"] == [1, 2, 4]
+    assert m.cond_stage_model.max_length == 80
+    c = m.model.diffusion_model.cfg
+    assert (c.hidden_size, c.depth, c.num_heads, c.max_len, c.num_experts, c.context_dim) == (768, 4, 8, 1500, 4, 768)
+    assert m.model.conditioning_key == "hybrid"
+    s = vm.CFMSampler(m, 1000)
+    assert s.num_timesteps == 1000 and s._shape(None, 3) == (3, 20, 750)
+    return cfg, [str(x.message) for x in w]
+
+
+def test_full_key_config_takes_the_reference_constructor_paths():
+    """configs/vocal2music_full.yaml (travels to the GPU box) carries every key of the reference's `model:` tree, including the
+    ones this path ignores and a dangling first-stage ckpt_path: same model as the trimmed config, a warning for the ckpt."""
+    cfg, warns = _check_boundary_config(os.path.join(ROOT, "configs", "vocal2music_full.yaml"))
+    assert any("ckpt_path" in x and "not found" in x for x in warns), warns
+    for k in ("linear_start", "linear_end", "num_timesteps_cond", "log_every_t", "cond_stage_trainable", "monitor", "use_ema", "scheduler_config"):
+        assert k in cfg.model.params, k
+    assert "lightning" in cfg and "data" in cfg and "test_dataset" in cfg
+    trimmed = vm.load_config(os.path.join(ROOT, "configs", "vocal2music.yaml"))
+    assert trimmed.model.params.unet_config == cfg.model.params.unet_config
+    assert trimmed.model.params.first_stage_config.params.ddconfig == cfg.model.params.first_stage_config.params.ddconfig
+    assert trimmed.model.params.cond_stage_config == cfg.model.params.cond_stage_config
+
+
+REF_YAML = "/root/reference/configs/vocal2music.yaml"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_YAML), reason="the reference checkout is not on this box")
+def test_reference_yaml_loads_unchanged():
+    """"the YAML file loads unchanged".  The reference's own configs/vocal2music.yaml:1-128 through the three calls of
+    initialize_model; and the committed full-key config must cover its whole `model:` key set, so the GPU box runs the same paths."""
+    cfg, warns = _check_boundary_config(REF_YAML)
+    assert any("ckpt_path" in x for x in warns)
+    ours = vm.load_config(os.path.join(ROOT, "configs", "vocal2music_full.yaml"))
+    ref_keys, our_keys = _model_keys(dict(cfg.model)), _model_keys(dict(ours.model))
+    assert ref_keys <= our_keys, sorted(ref_keys - our_keys)
+    assert set(cfg.keys()) <= set(ours.keys())
+    for k in ("unet_config", "cond_stage_config"):
+        assert cfg.model.params[k] == ours.model.params[k]
+    assert cfg.model.params.first_stage_config.params.ddconfig == ours.model.params.first_stage_config.params.ddconfig
