@@ -740,6 +740,11 @@ def main():
             name, bound, peak = cls_meta[cls]
             lpp = n / passes                          # launches per pass
             k = nt / lpp                              # how often each launch was timed
+            # "exact" holds only if every pass launched the same kernels and the event pool never ran dry (prof_start drops timings
+            # silently when it does): then lpp and k are whole numbers
+            if abs(lpp - round(lpp)) > 1e-9 or abs(k - round(k)) > 1e-9:
+                log(f"WARNING class '{name}': {n} launches over {passes} passes, {nt} timed - not every launch was timed equally often "
+                    f"(launches/pass {lpp:.3f}, times timed {k:.3f}); its per-pass figures are estimates")
             tf, tbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e12
             rows.append({"class": name, "bound": bound, "launches_per_pass": lpp, "timed_launches": nt, "times_each_launch_was_timed": k,
                          "avg_launch_us": 1e3 * ms / nt, "ms_per_pass": ms / k, "algorithmic_gflop_per_launch": fl / nt / 1e9,

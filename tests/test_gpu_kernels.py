@@ -421,48 +421,23 @@ def test_fp32_dma_conv_is_bit_identical_to_register_staged(lib, monkeypatch, B, 
     assert rel_l2(new, ref) < 2e-6, describe("conv1d fp32 dma", new, ref)
 
 
-_LOAD_CHILD = r'''
-import sys, time, torch
-a = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
-x = torch.randn(8, 256, 60000, device="cuda")
-a @ a
-torch.nn.functional.leaky_relu(x, 0.1)
-torch.cuda.synchronize()
-print("ready", flush=True)
-t0 = time.time()
-while time.time() - t0 < float(sys.argv[1]):
-    for _ in range(20):
-        a @ a
-        torch.nn.functional.leaky_relu(x, 0.1)
-    torch.cuda.synchronize()
-'''
-
-
 def test_one_tap_conv_is_stable_beside_a_second_gpu_process(lib):
     """Round 5: in front of the second-last ring step of a 1-tap layer on the 4-stage weight ring the counted vmcnt wait let the window's
     last DMA piece fly (conv1d_f32g.hip, `lag`): whole wrong 64 x 128 tiles, but only while something else kept the memory system busy -
     10-13 of 30 runs beside a second process, none alone (profiles/r05_conv_tail_race.txt), which is how two ranks sharing a GPU
     found it.  The shape of the VAE's attention scores at two clips (1536 -> 752 channels, k = 1: the tile choice takes 64 x 128 on the
     4-stage ring), repeated beside a process that streams HBM: every run has the first run's bits."""
-    import select
-    import subprocess
-    import sys
+    from tests.helpers import beside_load
     B, Ci, T, Co = 2, 1536, 752, 752
     x, w, b = dev(rnd((B, Ci, T), "sx")), rnd((Co, Ci, 1), "sw", 1.0 / Ci ** 0.5), dev(rnd((Co,), "sb"))
     wpk = dev(pack.pack_conv(w))
-    child = subprocess.Popen([sys.executable, "-c", _LOAD_CHILD, "45"], stdout=subprocess.PIPE, text=True)
-    try:
-        ready, _, _ = select.select([child.stdout], [], [], 240.0)          # (a fresh box pages torch in for a minute or two)
-        if not (ready and child.stdout.readline().strip() == "ready"):      # (no second process on this box: the repeats still run)
-            print("the load process did not start within 240 s - running the repeats without it")
+    with beside_load(45) as load:
         first = _conv_f32(lib, x, wpk, b, None, B, Ci, T, Co, 1, 1, 0, 0)
         ref = F.conv1d(x.double().cpu(), w.double(), b.double().cpu())
         assert rel_l2(first, ref) < 2e-6, describe("1x1 conv fp32", first, ref)
         bad = [i for i in range(200) if not torch.equal(_conv_f32(lib, x, wpk, b, None, B, Ci, T, Co, 1, 1, 0, 0), first)]
         assert not bad, f"runs {bad} of 200 differ from the first"
-    finally:
-        child.kill()
-        child.wait()
+        assert load.alive(), "the load process ended before the repeats did"
 
 
 @pytest.mark.parametrize("B,Ci,T,Co,k,u", [(2, 512, 24, 256, 16, 8), (1, 256, 32, 128, 15, 5), (2, 64, 52, 32, 4, 2), (1, 128, 20, 64, 8, 4)])

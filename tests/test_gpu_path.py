@@ -304,19 +304,23 @@ def test_fused_glue_launches_are_bit_identical(engines, monkeypatch):
     idx, dts = vm.euler_tables(4)   # 3 steps
     t_idx = torch.full((2 * B,), 640, dtype=torch.int64)
     outs = []
-    for knob in (None, "VB_BUCKET_COUNT_LAUNCH", "VB_EULER_LAUNCH"):
-        if knob:
-            monkeypatch.setenv(knob, "1")
+    try:
+        for knob in (None, "VB_BUCKET_COUNT_LAUNCH", "VB_EULER_LAUNCH"):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            L.load().vb_tune_reload()
+            cond = eng.precompute_cond(t5, inp["midi"], inp["beats"], T)
+            z1 = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=21)
+            z2 = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=22)      # a second call: tables as the first one left them
+            v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
+            torch.cuda.synchronize()
+            outs.append((z1.clone(), z2.clone(), v.clone(), r.clone()))
+            if knob:
+                monkeypatch.delenv(knob)
+    finally:                          # a failure mid-loop must not leave the knob in the library's cached tuning for the next tests
+        for knob in ("VB_BUCKET_COUNT_LAUNCH", "VB_EULER_LAUNCH"):
+            monkeypatch.delenv(knob, raising=False)
         L.load().vb_tune_reload()
-        cond = eng.precompute_cond(t5, inp["midi"], inp["beats"], T)
-        z1 = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=21)
-        z2 = eng.sample_cfg(inp["x_latent"], cond, idx, dts, 3.0, seed=22)      # a second call: tables as the first one left them
-        v, r = eng.forward(inp["x_latent"], t_idx, cond, seed=3, return_routes=True)
-        torch.cuda.synchronize()
-        outs.append((z1.clone(), z2.clone(), v.clone(), r.clone()))
-        if knob:
-            monkeypatch.delenv(knob)
-    L.load().vb_tune_reload()
     assert torch.isfinite(outs[0][0]).all() and not torch.equal(outs[0][0], outs[0][1])
     for k in (1, 2):
         for j, what in enumerate(("sample seed 21", "sample seed 22", "velocity", "routes")):

@@ -288,6 +288,9 @@ __global__ void __launch_bounds__(256, 3) conv1d_f32g_kernel(const ConvDev p) { 
         // the step's first MFMA costs matrix-pipe time (tools/probe/f32_loop_probe: 151 -> 142 TF/s for ~50 dependent scalar
         // instructions per 32 MFMAs).  Same tiles in the same order: bit-identical.
         static_assert(NT >= NSW - 1, "a step issues the tile NSW - 1 ahead: it lies in this chunk or the next one");
+        // (the same bound keeps the J == 0 wait below right: min(AH, NT) * WPW equals the runtime loop's (ahead_all - lag) form only while
+        //  NT >= NSW - 2, i.e. lag <= 0 - an NT = 1 / 2 instance on the 4-stage ring would bring back the round-5 tail race)
+        static_assert(NT >= NSW - 2, "unrolled-tap wait count assumes no lag between the window and its first weight tile");
         const unsigned xa0 = lds_u32(lx + aoff + wn * TN * 32 + l31 + g * XP);
         const unsigned wa0 = lds_u32(lw + wm * TM * 32 + l31 + g * CO_TILE);
         const int dil4 = p.dil * 4;
