@@ -52,7 +52,7 @@ CLASS_KERNELS = {0: ("gemm_bf16", "band_ffn", "moe_ffn", "moe_w2"), 1: ("attn_ke
 
 def classes_for(vocoder_precision):
     c = dict(CLASSES)
-    if vocoder_precision == "fp32":
+    if vocoder_precision in ("fp32", "fp32mf"):
         c.update(CLASSES_FP32)
     return c
 
@@ -337,7 +337,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=None, help="clip length in seconds (default 20; 120 for c5)")
     ap.add_argument("--flow-steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "split"])
-    ap.add_argument("--vocoder-precision", default="both", choices=["both", "fp32", "split"],
+    ap.add_argument("--vocoder-precision", default="both", choices=["both", "fp32", "split", "fp32mf"],
                     help="VAE + vocoder arithmetic: 'fp32' = the literal 'fp32 vocoder' of configs[1] on v_mfma_f32_32x32x2_f32 (157 TFLOP/s roof); "
                          "'split' = fp32 I/O, every product as bf16 hi/lo pairs on the bf16 MFMA pipe (bf16x3, <= 3e-5 of exact fp32; priced "
                          "against bf16 peak / 3); 'both' (default) = the timed region runs with fp32 (`value`, configs[1] as written) and then a "
@@ -726,7 +726,7 @@ def main():
     EVERY, EVERY_OTHER, PROF_PASSES = 7, 2, 14
     table, table_sec, dominant = [], [], 0
     GROUPS = {"bf16 MFMA GEMMs of the DiT (projections, routed + band experts)": (0,), "bf16 flash attention (self + T5 cross)": (1,),
-              f"VAE + vocoder convolutions in {'exact fp32 (v_mfma_f32_32x32x2_f32)' if prim == 'fp32' else 'split-bf16 (bf16x3)'}: implicit-GEMM conv1d + "
+              f"VAE + vocoder convolutions in {'exact fp32 (v_mfma_f32_32x32x2_f32)' if prim == 'fp32' else 'fp32 with F(2,3) minimal filtering (v_mfma_f32_32x32x2_f32)' if prim == 'fp32mf' else 'split-bf16 (bf16x3)'}: implicit-GEMM conv1d + "
               "fused HiFi-GAN ResBlock pairs": (2, 3)}
     groups, dom_group = [], None
 
@@ -956,12 +956,15 @@ def main():
             "vs_baseline": None,
             "dtype": ("bf16 DiT (fp32 accumulate)" if args.precision == "bf16" else "bf16x3 split DiT") +
                      (" + fp32-I/O VAE/vocoder on split-bf16 (bf16x3) MFMA, <=3e-5 of exact fp32" if prim == "split" else
-                      " + fp32 VAE/vocoder (v_mfma_f32_32x32x2_f32, exact fp32 products)"),
+                      " + fp32 VAE/vocoder (v_mfma_f32_32x32x2_f32, fp32 products; F(2,3) minimal filtering on the stride-1 k = 3 / 7 / 11 layers)"
+                      if prim == "fp32mf" else " + fp32 VAE/vocoder (v_mfma_f32_32x32x2_f32, exact fp32 products)"),
             "data": "synthetic (seeded PRNG clips, random-init checkpoints of the configured architecture)",
             "config": {"workload": wl + f", {args.flow_steps} Euler steps x 2 NFE (CFG scale {args.scale}), Band-MoE E={args.experts}, "
                                         "VAE decode + HiFi-GAN V1-like (8*5*4*2), configs/vocal2music.yaml; VAE / vocoder arithmetic: " +
                                         ("split-bf16 (bf16x3 products, fp32 I/O and accumulation, <= 3e-5 of exact fp32; `--vocoder-precision fp32` "
                                          "runs the literal fp32 kernels)" if prim == "split" else
+                                         "fp32 on the f32 MFMA with F(2,3) minimal filtering (fp32 products, ~1.45x fewer on the layers it applies to; "
+                                         "<= 2e-6 of the direct fp32 kernels)" if prim == "fp32mf" else
                                          "exact fp32 (f32 MFMA, configs[1] as written)" + ("; the same K passes with the bf16x3 VAE / vocoder are timed in a "
                                                                                             "second region and reported under `split`" if sec else "")),
                        "vocoder_precision": prim,

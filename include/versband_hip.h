@@ -207,7 +207,10 @@ typedef struct {
     float in_slope, out_slope, alpha, beta, acc_scale;
     const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
     const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution (w_x3 == NULL: exact-fp32 pair, w and w2_x3 are the fp32
-                                              * packed [k][Ci][Co] weights of the two convolutions; channels 32 / 64 / 128) */
+                                              * packed [k][Ci][Co] weights of the two convolutions; channels 32 / 64 / 128).
+                                              * VB_OP_CONV with w_x3 == NULL: optional fp32 minimal-filtering weights [P][Ci][Co] of the
+                                              * same filter (versband_amd/pack.py:pack_conv_mf) - the layer then runs conv1d_f32w_kernel
+                                              * (fp32 products, F(2,3): ~1.4-1.5x fewer of them) where its conditions hold */
     int in_stride, in_phase;                 /* VB_OP_CONV: the convolution reads x[i*in_stride + in_phase] (0/1 = plain) */
     int x_planes;                            /* VB_OP_CONV: x is a VB_OP_XT_PLANES buffer (upsample2 then describes how it was made) */
 } vb_net_op;
@@ -311,6 +314,12 @@ int vb_attention(const void* q, const void* k, const void* vt, const void* ky, c
 int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil, int pad,
                   int tr_stride, int tr_pad, int tr_k, int T_out, int in_act, float in_slope, const float* res, float* out,
                   const void* w_x3, int ci_pad, void* stream);
+/* Conv1d in fp32 with 1-D minimal filtering (conv1d_f32w.hip; the HiFi-GAN ResBlock convolutions, vocoder/hifigan/modules/hifigan.py:27-64):
+ * out = beta*out + alpha*(conv_{k,dil,pad}(act(x)) + bias + res); w = packed [k][Ci][Co] (the fallback when the layer is not eligible),
+ * w_mf = the same filter as F(2,3) pseudo-taps [P][Ci][Co] (pack.py:pack_conv_mf).  k = 3 / 5 / 7 / 11, stride 1, Ci % 16 == 0, Co >= 64,
+ * T % 4 == 0.  Agrees with vb_conv1d_f32 to fp32 roundoff, not bit for bit. */
+int vb_conv1d_f32_mf(const float* x, const float* w, const float* w_mf, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil,
+                     int pad, int T_out, int in_act, float in_slope, const float* res, float alpha, float beta, float* out, void* stream);
 /* HiFi-GAN ResBlock1 pair in exact fp32, one launch (vocoder/hifigan/modules/hifigan.py:27-64; respair_f32.hip):
  * out = beta*out + alpha*(x + b2 + conv2_{k,1}(lrelu(b1 + conv1_{k,dil}(lrelu(x))))), x / out [B][C][T] (distinct buffers), weights fp32
  * packed [k][C ci][C co]; C = 32 / 64 / 128, odd k <= 17, (k-1)*dil <= 60, T % 4 == 0.  Equals two vb_conv1d_f32 launches bit for bit. */

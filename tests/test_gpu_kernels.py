@@ -421,6 +421,76 @@ def test_fp32_dma_conv_is_bit_identical_to_register_staged(lib, monkeypatch, B, 
     assert rel_l2(new, ref) < 2e-6, describe("conv1d fp32 dma", new, ref)
 
 
+MF_CASES = [(2, 128, 1000, 128, 3, 1, 1, True), (1, 256, 752, 256, 3, 3, 1, False), (2, 128, 488, 128, 3, 5, 1, True),
+            (1, 128, 1204, 128, 7, 1, 1, True), (2, 256, 360, 256, 7, 3, 1, False), (1, 128, 600, 128, 7, 5, 0, True),
+            (1, 256, 724, 256, 11, 1, 1, True), (2, 128, 500, 128, 11, 3, 1, False), (1, 128, 1000, 128, 11, 5, 1, True),
+            (1, 64, 2000, 128, 11, 5, 1, True), (1, 384, 304, 192, 3, 1, 0, True), (2, 96, 244, 160, 5, 2, 1, False), (1, 128, 120, 128, 7, 3, 1, True)]
+
+
+@pytest.mark.parametrize("B,Ci,T,Co,k,dil,act,res", MF_CASES)
+def test_fp32_minimal_filtering_conv_matches_the_direct_kernel(lib, B, Ci, T, Co, k, dil, act, res):
+    """conv1d_f32w_kernel (round 6): the HiFi-GAN ResBlock convolutions (vocoder/hifigan/modules/hifigan.py:27-64) as F(2,3) minimal
+    filtering - pseudo-tap weights pre-combined by pack.pack_conv_mf, outputs formed in the epilogue.  fp32 products on the f32 MFMA,
+    1.4-1.5x fewer of them; NOT bit-identical to the direct kernel but equally close to float64: both within 2e-6 (rel-L2), and
+    the two differ by < 4e-6 of the output's max (measured 0.5-2e-6: two fp32 summation orders).  Covers every (k, dilation) of the generator, partial last tiles, T not a multiple of the
+    tile, clip ends (padding), Ci != Co, the accumulate-into form and k = 5 (group + pair remainder)."""
+    x, w, b = dev(rnd((B, Ci, T), "mx")), rnd((Co, Ci, k), "mw", 1.0 / (Ci * k) ** 0.5), dev(rnd((Co,), "mb"))
+    r = dev(rnd((B, Co, T), "mr")) if res else None
+    pad = (k - 1) * dil // 2
+    wpk, wmf = dev(pack.pack_conv(w)), dev(pack.pack_conv_mf(w))
+    assert wmf.shape == (pack.mf_pseudo_taps(k), Ci, Co)
+    direct = _conv_f32(lib, x, wpk, b, r, B, Ci, T, Co, k, dil, pad, act)
+    old = dev(rnd((B, Co, T), "mo"))
+    for alpha, beta in ((1.0, 0.0), (1.0 / 3, 1.0)):
+        out = old.clone() if beta else torch.full((B, Co, T), float("nan"), device="cuda")
+        L.check(lib.vb_conv1d_f32_mf(L.ptr(x), L.ptr(wpk), L.ptr(wmf), L.ptr(b), B, Ci, T, Co, k, dil, pad, T, act, 0.1,
+                                     L.ptr(r) if r is not None else None, alpha, beta, L.ptr(out), L.stream_ptr()), "conv mf")
+        sync()
+        xin = F.leaky_relu(x.double().cpu(), 0.1) if act else x.double().cpu()
+        ref = F.conv1d(xin, w.double(), b.double().cpu(), dilation=dil, padding=pad)
+        if res:
+            ref = ref + r.double().cpu()
+        full = ref
+        ref = alpha * ref + beta * old.double().cpu() if beta else ref
+        assert torch.isfinite(out).all()
+        assert rel_l2(out, ref) < 2e-6, describe(f"conv1d fp32 mf alpha={alpha:.3f}", out, ref)
+        if not beta:
+            assert rel_l2(direct, full) < 2e-6
+            assert float((out - direct).abs().max()) < 4e-6 * float(full.abs().max()), describe("mf vs direct", out, direct)
+
+
+def test_fp32_minimal_filtering_switches(lib, monkeypatch):
+    """VB_MF_OCC=2 runs the same kernel built for two workgroups per CU: same bits as the three-per-CU build.  VB_CONV_MF_OFF=1 ignores
+    the minimal-filtering weights: the call is the direct fp32 kernel, bit for bit."""
+    B, C, T, k, dil = 2, 128, 1000, 11, 3
+    x, w, b = dev(rnd((B, C, T), "sx2")), rnd((C, C, k), "sw2", 1.0 / (C * k) ** 0.5), dev(rnd((C,), "sb2"))
+    pad = (k - 1) * dil // 2
+    wpk, wmf = dev(pack.pack_conv(w)), dev(pack.pack_conv_mf(w))
+
+    def mf():
+        out = torch.full((B, C, T), float("nan"), device="cuda")
+        L.check(lib.vb_conv1d_f32_mf(L.ptr(x), L.ptr(wpk), L.ptr(wmf), L.ptr(b), B, C, T, C, k, dil, pad, T, 1, 0.1, None, 1.0, 0.0,
+                                     L.ptr(out), L.stream_ptr()), "conv mf")
+        sync()
+        return out
+
+    direct = _conv_f32(lib, x, wpk, b, None, B, C, T, C, k, dil, pad, 1)
+    base = mf()
+    assert not torch.equal(base, direct) and float((base - direct).abs().max()) < 4e-6 * float(direct.abs().max())
+    try:
+        monkeypatch.setenv("VB_MF_OCC", "2")
+        lib.vb_tune_reload()
+        assert torch.equal(mf(), base)
+        monkeypatch.delenv("VB_MF_OCC")
+        monkeypatch.setenv("VB_CONV_MF_OFF", "1")
+        lib.vb_tune_reload()
+        assert torch.equal(mf(), direct)
+    finally:
+        monkeypatch.delenv("VB_MF_OCC", raising=False)
+        monkeypatch.delenv("VB_CONV_MF_OFF", raising=False)
+        lib.vb_tune_reload()
+
+
 def test_one_tap_conv_is_stable_beside_a_second_gpu_process(lib):
     """Round 5: in front of the second-last ring step of a 1-tap layer on the 4-stage weight ring the counted vmcnt wait let the window's
     last DMA piece fly (conv1d_f32g.hip, `lag`): whole wrong 64 x 128 tiles, but only while something else kept the memory system busy -

@@ -12,13 +12,20 @@ timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $
 echo "gpu tests exit: $?" >> $O/gpu_tests.log
 tail -4 $O/gpu_tests.log
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -2 | tee $O/smoke.log
-timeout 600 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-timeout 300 python bench.py --batch 1 --streams 1 --steps 4 --warmup 2 --no-cpu-baseline --no-pmc > $O/bench_b1.json 2> $O/bench_b1.err
-timeout 300 python bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-isolated > $O/bench_s1.json 2> $O/bench_s1.err
-for f in c2 b1 s1; do python - <<PY
+# (the stdout line of every run is the <= 4 KB driver line -> bench_<f>.line.json; the tables are in the side file bench_<f>.json)
+timeout 600 python bench.py --detail $O/bench_c2.json > $O/bench_c2.line.json 2> $O/bench_c2.err
+timeout 300 python bench.py --batch 1 --streams 1 --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --detail $O/bench_b1.json > $O/bench_b1.line.json 2> $O/bench_b1.err
+timeout 300 python bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-isolated --detail $O/bench_s1.json > $O/bench_s1.line.json 2> $O/bench_s1.err
+if [ "${2:-}" = "all" ]; then
+  timeout 400 python bench.py --workload c3 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --detail $O/bench_c3.json > $O/bench_c3.line.json 2> $O/bench_c3.err
+  timeout 400 python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline --no-pmc --detail $O/bench_c5.json > $O/bench_c5.line.json 2> $O/bench_c5.err
+fi
+for f in c2 b1 s1 c3 c5; do [ -f $O/bench_$f.json ] || continue; python - <<PY
 import json
 try:
-    d=json.loads([l for l in open('$O/bench_$f.json') if l.startswith('{')][-1])
+    line=[l for l in open('$O/bench_$f.line.json') if l.startswith('{')][-1]
+    assert len(line) <= 4097, len(line)
+    d=json.load(open('$O/bench_$f.json'))
     sp=d.get('split') or {}
     pr=d['roofline'].get('path_roofline') or {}
     print('$f', 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],2), 'frac', round(d['roofline']['frac'],4), 'path', pr.get('frac') and round(pr['frac'],4), 'parity', d['parity_check'] and d['parity_check']['ok'],

@@ -12,7 +12,7 @@ HAVE=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null ||
 echo "visible GPUs: $HAVE"
 for n in $GPUS; do
   if [ "$n" -gt "$HAVE" ]; then echo "N=$n: skipped ($HAVE GPUs visible)"; continue; fi
-  timeout 1200 python bench.py --gpus $n --steps $STEPS --warmup $WARM --no-cpu-baseline --no-pmc --no-isolated > $O/n$n.json 2> $O/n$n.err
+  timeout 1200 python bench.py --gpus $n --steps $STEPS --warmup $WARM --no-cpu-baseline --no-pmc --no-isolated --detail $O/n$n.detail.json > $O/n$n.json 2> $O/n$n.err
   echo "N=$n exit $?"; grep '^{' $O/n$n.json | tail -1
 done
 python - <<PY
@@ -25,7 +25,7 @@ for n in "$GPUS".split():
     ls = [l for l in open(p) if l.startswith("{")]
     if not ls:
         print(f"N={n}: no JSON line (see $O/n{n}.err)"); continue
-    d = json.loads(ls[-1]); r = d["ranks"]
+    d = json.load(open(f"$O/n{n}.detail.json")); r = d["ranks"]      # the stdout line is the <= 4 KB summary; the side file has the rank table
     base = base or d["value"] / d["n_gpus"]
     pr = r["per_rank_ms"]
     print(f"N={d['n_gpus']}: {d['value']:9.1f} mel-s/s  {d['ms_per_step']:7.2f} ms/step  scaling {d['value'] / base:5.2f}x of N=1  ranks {min(pr):.1f}..{max(pr):.1f} ms"

@@ -19,6 +19,7 @@ struct ConvDev {
     const bf16_t* wp; int64_t wp_plane; int Ci_pad;   // split-bf16 weights [2 planes][phase][tap][Co][Ci_pad]
     int64_t wp_bstride;
     const bf16_t* xt; int64_t xt_plane; int xt_Tp;     // pre-activated transposed split planes of the input (XT mode)
+    const float* ww;         // conv1d_f32w_kernel: minimal-filtering (F(2,3)) pseudo-tap weights [P][Ci][Co], pack.py:pack_conv_mf
     int stage_epi;           // [b][co][t] output, stride 1, T_out % 4 == 0, 16-B aligned rows: the staged (16-B lane) epilogue
 #ifdef VB_EXPERIMENTS
     int old_tail_wait;       // conv1d_f32g: the round-4 wait count in front of a chunk's first tap (A/B of the round-5 fix)
@@ -178,3 +179,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvDev& p, f32x16 (&acc)[TM
 // halo <= 60, 16-byte aligned rows unless upsample2)
 #define GK 16                      // input channels per chunk (= CK: the accumulation order of conv1d_f32_kernel)
 void launch_conv1d_f32g(ConvDev& d, int n_count, int B, int upsample2, hipStream_t st);
+// conv1d_f32w.hip: the same rings with F(2,3) minimal filtering (k = 3 / 5 / 7 / 11, stride 1): fp32 products, ~1.4-1.5x fewer of them
+bool conv1d_f32w_supported(int ksize, int dil);
+int conv1d_f32w_pseudo_taps(int ksize);
+void launch_conv1d_f32w(ConvDev& d, int B, hipStream_t st);

@@ -489,15 +489,24 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
         g.prof_class = 2;
         return launch_gemm(g, st);
     }
-    const double taps_eff = a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize;
-    ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * taps_eff,
-                   4.0 * a.B * ((double)a.Ci * a.T_in * (a.xt ? 1.0 : 1.0) + (double)a.Co * a.T_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.beta != 0.f ? 1.0 : 0.0)))
-                       + 4.0 * (double)a.Co * a.Ci * (a.tr_stride > 1 ? a.tr_k : a.ksize), st);
     // staged epilogue (split-bf16 kernel): plain [b][co][t] output whose rows start 16-B aligned
     d.stage_epi = (a.tr_stride <= 1 && !a.out_transposed && a.T_out % 4 == 0 && a.out_bstride % 4 == 0 &&
                    (!a.res || a.res_bstride % 4 == 0) && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                    (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) && !vb_tune().conv_direct_epi) ? 1 : 0;
-    if (a.Co == 1 && a.w && !a.w_bstride && !a.x_bmod && d.phases == 1 && d.in_stride == 1 && !a.upsample2 && !a.out_transposed &&
+    // minimal filtering (conv1d_f32w_kernel): the DMA-fed fp32 kernel's conditions + stride 1, shared weights, the staged epilogue, wide layers
+    const bool use_mf = a.w_mf && !a.wp && !a.w_bstride && !a.x_bmod && d.in_stride == 1 && d.phases == 1 && !a.upsample2 &&
+                        (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && a.Ci % GK == 0 && a.Co % 4 == 0 && a.Co >= 128 && d.stage_epi &&
+                        conv1d_f32w_supported(a.ksize, a.dil) && a.T_in % 4 == 0 && a.x_bstride % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w_mf) & 15) == 0 && !vb_tune().conv_mf_off;
+    // (flops of the profiler's class table: EXECUTED MFMA work - the minimal-filtering kernel runs pseudo-taps / 2 products per output)
+    const double taps_eff = use_mf ? 0.5 * conv1d_f32w_pseudo_taps(a.ksize) : (a.tr_stride > 1 ? (double)a.tr_k / a.tr_stride : (double)a.ksize);
+    ProfScope prof(2, 2.0 * a.B * a.Co * a.Ci * (double)a.T_out * taps_eff,
+                   4.0 * a.B * ((double)a.Ci * a.T_in * (a.xt ? 1.0 : 1.0) + (double)a.Co * a.T_out * (1.0 + (a.res ? 1.0 : 0.0) + (a.beta != 0.f ? 1.0 : 0.0)))
+                       + 4.0 * (double)a.Co * a.Ci * (a.tr_stride > 1 ? a.tr_k : a.ksize), st);
+    if (use_mf) {
+        d.ww = a.w_mf;
+        launch_conv1d_f32w(d, a.B, st);
+    } else if (a.Co == 1 && a.w && !a.w_bstride && !a.x_bmod && d.phases == 1 && d.in_stride == 1 && !a.upsample2 && !a.out_transposed &&
         (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && !vb_tune().conv_f32_old) {
         hipLaunchKernelGGL(conv1d_co1_kernel, dim3(cdiv(a.T_out, C1_TT), a.B), dim3(256), 0, st, d);       // (VB_CONV_F32_OLD=1: the MFMA kernels)
     } else if (a.wp && (!a.w_bstride || a.wp_bstride)) {

@@ -49,6 +49,7 @@ static void tune_load() {
     t.bucket_count_launch = getenv("VB_BUCKET_COUNT_LAUNCH") != nullptr;
     t.euler_launch = getenv("VB_EULER_LAUNCH") != nullptr;
     t.conv_f32_rt_taps = getenv("VB_CONV_F32_RT_TAPS") != nullptr;
+    t.conv_mf_off = getenv("VB_CONV_MF_OFF") != nullptr; t.conv_mf_occ = env_int("VB_MF_OCC", 3);        // minimal-filtering weights ignored: the direct fp32 kernels (A/B)
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels
@@ -729,6 +730,8 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
                 const int phases = o.tr_stride > 1 ? o.tr_stride : 1;
                 const int ntaps = o.tr_stride > 1 ? (o.tr_k + o.tr_stride - 1) / o.tr_stride : o.ksize;
                 a.wp = (const bf16_t*)o.w_x3; a.Ci_pad = o.ci_pad; a.wp_plane = (int64_t)phases * ntaps * a.Co * o.ci_pad;
+            } else if (o.w2_x3 && o.w_buf == -1) {
+                a.w_mf = (const float*)o.w2_x3;        // fp32 minimal-filtering weights (VB_OP_CONV, w_x3 == NULL): conv1d_f32w_kernel where it applies
             }
             VB_TRY(launch_conv1d(a, st));
         } else if (o.kind == VB_OP_GN_APPLY) {
@@ -1255,6 +1258,15 @@ int vb_conv1d_f32(const float* x, const float* w, const float* bias, int B, int 
     a.x = x; a.x_bstride = (int64_t)Ci * T_in; a.Ci = Ci; a.T_in = T_in; a.w = w; a.bias = bias; a.Co = Co; a.ksize = ksize;
     a.dil = dil; a.pad = pad; a.in_act = in_act; a.in_slope = in_slope; a.out = out; a.out_bstride = (int64_t)Co * T_out;
     a.T_out = T_out; a.res = res; a.res_bstride = (int64_t)Co * T_out; a.B = B; a.tr_stride = tr_stride; a.tr_pad = tr_pad; a.tr_k = tr_k;
+    return launch_conv1d(a, (hipStream_t)stream);
+}
+int vb_conv1d_f32_mf(const float* x, const float* w, const float* w_mf, const float* bias, int B, int Ci, int T_in, int Co, int ksize, int dil,
+                     int pad, int T_out, int in_act, float in_slope, const float* res, float alpha, float beta, float* out, void* stream) {
+    if (!x || !w || !w_mf || !out || B < 1 || T_in < 1) VB_FAIL(VB_E_INVALID, "conv1d_f32_mf: null pointer or B/T < 1");
+    ConvArgs a;
+    a.x = x; a.x_bstride = (int64_t)Ci * T_in; a.Ci = Ci; a.T_in = T_in; a.w = w; a.w_mf = w_mf; a.bias = bias; a.Co = Co; a.ksize = ksize;
+    a.dil = dil; a.pad = pad; a.in_act = in_act; a.in_slope = in_slope; a.out = out; a.out_bstride = (int64_t)Co * T_out;
+    a.T_out = T_out; a.res = res; a.res_bstride = (int64_t)Co * T_out; a.B = B; a.alpha = alpha; a.beta = beta;
     return launch_conv1d(a, (hipStream_t)stream);
 }
 int vb_respair_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C, int T, int k, int dil,

@@ -123,6 +123,8 @@ struct ConvArgs {
     // optional pre-activated transposed split planes of the input (xt_planes_kernel): [2][B][xt_rows(T_in)][Ci]; x / in_act /
     // GroupNorm fields are then ignored and the window is DMA'd straight into LDS
     const bf16_t* xt = nullptr;
+    // optional minimal-filtering weights [P][Ci][Co] fp32 (pack.py:pack_conv_mf): selects conv1d_f32w_kernel (fp32 products, F(2,3)) where it applies
+    const float* w_mf = nullptr;
 };
 int launch_conv1d(const ConvArgs& a, hipStream_t st);
 // fused HiFi-GAN ResBlock1 pair (respair_x3.hip): out = beta*out + alpha*(x + b2 + conv2(lrelu(b1 + conv1_dil(lrelu(x)))))

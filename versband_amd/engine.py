@@ -264,9 +264,12 @@ class NetBuilder:
     """Flattens a conv network into the vb_net_op list executed by the C++ runtime."""
 
     def __init__(self, device, precision: str = "split"):
-        assert precision in ("split", "fp32")
+        assert precision in ("split", "fp32", "fp32mf")
         self.device = device
-        self.precision = precision      # "split": bf16x3 MFMA conv kernel (fp32-class); "fp32": exact f32 MFMA kernel
+        # "split": bf16x3 MFMA conv kernel (fp32-class); "fp32": exact f32 MFMA kernel; "fp32mf": the fp32 op list with F(2,3) minimal
+        # filtering on the stride-1 k = 3 / 5 / 7 / 11 convolutions of >= 128 output channels (one tile shape: 128 co; narrower layers are faster direct) (fp32 products, ~1.45x fewer; conv1d_f32w.hip)
+        self.mf = precision == "fp32mf"
+        self.precision = "fp32" if self.mf else precision
         self.ops: List[L.NetOp] = []
         self.bufs: List[Tuple[int, int, int]] = []
         self.free: Dict[Tuple[int, int, int], List[int]] = {}
@@ -355,7 +358,12 @@ class NetBuilder:
             planes, ci_pad = pack.pack_conv_x3(w.to(self.device))
             self.keep.append(planes)
             w_x3 = planes.data_ptr()
-        op = L.NetOp(kind=L.OP_CONV, x=x, out=out, res=res, stats=stats, w_buf=w_buf, w=self._t(w), bias=self._t(bias),
+        w_mf = None
+        if (self.mf and w is not None and w_buf == -1 and tr_stride == 1 and in_stride == 1 and not upsample2 and not out_transposed and
+                k in (3, 5, 7, 11) and (k - 1) * dil <= 60 and dil <= 8 and Ci % 16 == 0 and Co % 4 == 0 and Co >= 128 and
+                in_act in (L.ACT_NONE, L.ACT_LRELU) and w.shape == (k, Ci, Co)):
+            w_mf = self._t(pack.pack_conv_mf(w.permute(2, 1, 0)))          # (w arrives packed [k][Ci][Co])
+        op = L.NetOp(kind=L.OP_CONV, x=x, out=out, res=res, stats=stats, w_buf=w_buf, w=self._t(w), bias=self._t(bias), w2_x3=w_mf,
                      gn_gamma=self._t(gamma), gn_beta=self._t(beta_gn), Ci=Ci, Co=Co, ksize=k, dil=dil, pad=pad,
                      upsample2=upsample2, in_act=in_act, out_act=out_act, out_transposed=out_transposed, tr_stride=tr_stride,
                      tr_pad=tr_pad, tr_k=tr_k, gn_groups=groups, in_slope=in_slope, out_slope=out_slope, alpha=alpha, beta=beta,

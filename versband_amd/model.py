@@ -264,7 +264,7 @@ class CFM:
         self.cond_stage_forward = None
         self.scale_factor = torch.tensor(float(scale_factor))
         self.precision = precision
-        assert vocoder_precision in ("fp32", "split"), vocoder_precision
+        assert vocoder_precision in ("fp32", "split", "fp32mf"), vocoder_precision
         self.vocoder_precision = vocoder_precision
         self.first_stage_model._precision = vocoder_precision
         self.device = torch.device("cpu")
@@ -506,7 +506,7 @@ class HifiGAN:
     def __init__(self, vocoder_ckpt, device=None, precision="fp32"):
         """vocoder/hifigan/hifigan.py:7-18.  precision: "fp32" = the reference's arithmetic (f32 MFMA; default since round 4),
         "split" = bf16x3 (<= 3e-5 of it, faster)"""
-        assert precision in ("fp32", "split"), precision
+        assert precision in ("fp32", "split", "fp32mf"), precision
         self.precision = precision
         base_dir = vocoder_ckpt
         self.config = set_hparams(f"{base_dir}/config.yaml")
@@ -562,7 +562,7 @@ class VocoderBigVGAN:
 
     def __init__(self, ckpt_vocoder, device="cuda", precision="fp32"):
         import yaml
-        assert precision in ("fp32", "split"), precision
+        assert precision in ("fp32", "split", "fp32mf"), precision
         self.precision = precision
         sd = torch.load(os.path.join(ckpt_vocoder, "best_netG.pt"), map_location="cpu")
         self.state = {k: v for k, v in sd["generator"].items() if not k.endswith("filter")}     # the filters are recomputed

@@ -35,6 +35,30 @@ def pack_conv(w: Tensor) -> Tensor:
     return w.float().permute(2, 1, 0).contiguous()
 
 
+def mf_pseudo_taps(k: int) -> int:
+    """pseudo-taps of a k-tap filter under F(2,3) minimal filtering: 4 per group of three taps, 2 for a lone tap, 3 for a pair."""
+    return 4 * (k // 3) + (2 if k % 3 == 1 else 3 if k % 3 == 2 else 0)
+
+
+def pack_conv_mf(w: Tensor) -> Tensor:
+    """Conv1d weight [Co,Ci,k] -> F(2,3) minimal-filtering pseudo-taps [P][Ci][Co] fp32 (csrc/conv1d_f32w.hip, same enumeration as its
+    mf_tap()): per group of three taps (w0, w1, w2): w0, (w0+w1+w2)/2, (w0-w1+w2)/2, w2; a lone last tap w: w, -w; a last pair (w0, w1):
+    w0, w0+w1, -w1.  Combined in float64, rounded once."""
+    co, ci, k = w.shape
+    w = w.detach().double().cpu()
+    taps = []
+    for g in range(k // 3):
+        w0, w1, w2 = w[:, :, 3 * g], w[:, :, 3 * g + 1], w[:, :, 3 * g + 2]
+        taps += [w0, (w0 + w1 + w2) / 2, (w0 - w1 + w2) / 2, w2]
+    o = 3 * (k // 3)
+    if k % 3 == 1:
+        taps += [w[:, :, o], -w[:, :, o]]
+    elif k % 3 == 2:
+        taps += [w[:, :, o], w[:, :, o] + w[:, :, o + 1], -w[:, :, o + 1]]
+    assert len(taps) == mf_pseudo_taps(k)
+    return torch.stack([t.t() for t in taps]).float().contiguous()
+
+
 def pack_conv_transpose(w: Tensor, stride: int) -> Tensor:
     """ConvTranspose1d weight [Ci,Co,k] -> polyphase [stride][Kmax][Ci][Co]:
     tap j of phase p holds W[:, :, p + stride*(Kmax-1-j)] (zero when that index >= k)."""
