@@ -5,8 +5,9 @@ A "step" = one pass of the whole hot path over one batch of synthetic clips that
 resident in HBM: conditioning precompute -> Euler flow steps with CFG (2 network evaluations
 per step, batched) -> VAE decode -> full HiFi-GAN decode.
 
-  --workload c2 (default)  BASELINE configs[1]: batch 8 x 20 s clips, 50 flow steps, bf16 DiT + fp32 VAE/vocoder (`value`); the same passes with
-                           the bf16x3 VAE/vocoder are timed in a second region (`split`)
+  --workload c2 (default)  BASELINE configs[1]: batch 8 x 20 s clips, 50 flow steps, bf16 DiT + fp32 VAE/vocoder (`value`: fp32 products on the f32 MFMA,
+                           F(2,3) minimal filtering where it applies); the same passes with the direct fp32 kernels (`fp32_direct`) and the
+                           bf16x3 VAE/vocoder (`split`) are timed in their own regions
   --workload c3            BASELINE configs[2]: Band-MoE stress, num_experts = 8, batch 32 (48 128 token rows per CFG branch)
   --workload c5            BASELINE configs[4]: long-form, batch 4 x 120 s (T = 4500 latent frames in windows of 1500 tokens,
                            cross-faded) + VAE decode of the whole latent + halo'd chunked vocoding
@@ -122,10 +123,14 @@ def compact_line(out: dict, detail_path: str | None) -> str:
                                 "sample": (cb.get("sample") or "")[:300], "reference_faithful": _r(rfa.get("value"), 4)}
         if cb.get("error"):
             line["cpu_baseline"]["error"] = str(cb["error"])[:200]
-    sp = out.get("split")
-    if sp is not None:
-        line["split"] = {"value": _r(sp.get("value")), "ms_per_step": _r(sp.get("ms_per_step")), "vocoder_precision": sp.get("vocoder_precision"),
+    for key in ("fp32_direct", "split"):
+        sp = out.get(key)
+        if sp is not None:
+            line[key] = {"value": _r(sp.get("value")), "ms_per_step": _r(sp.get("ms_per_step")), "vocoder_precision": sp.get("vocoder_precision"),
                          "parity_ok": (sp.get("parity_check") or {}).get("ok")}
+    deq = rf.get("direct_equivalent")
+    if deq:
+        line["roofline"]["direct_equivalent"] = {"achieved": _r(deq.get("achieved")), "frac": _r(deq.get("frac"), 4)}
     rk = out.get("ranks") or {}
     if (rk.get("world") or 1) > 1:
         line["ranks"] = {"backend": rk.get("backend"), "weight_broadcast_ms": _r(rk.get("weight_broadcast_ms"), 4),
@@ -134,7 +139,7 @@ def compact_line(out: dict, detail_path: str | None) -> str:
     line["detail"] = detail_path
     s = json.dumps(line, separators=(",", ":"))
     # belt and braces: shed optional blocks before ever exceeding the limit (never the contract keys, roofline or cpu_baseline)
-    for drop in ("ranks", "split", "data"):
+    for drop in ("ranks", "split", "fp32_direct", "data"):
         if len(s) <= LINE_MAX:
             break
         line.pop(drop, None)
@@ -340,8 +345,9 @@ def parse():
     ap.add_argument("--vocoder-precision", default="both", choices=["both", "fp32", "split", "fp32mf"],
                     help="VAE + vocoder arithmetic: 'fp32' = the literal 'fp32 vocoder' of configs[1] on v_mfma_f32_32x32x2_f32 (157 TFLOP/s roof); "
                          "'split' = fp32 I/O, every product as bf16 hi/lo pairs on the bf16 MFMA pipe (bf16x3, <= 3e-5 of exact fp32; priced "
-                         "against bf16 peak / 3); 'both' (default) = the timed region runs with fp32 (`value`, configs[1] as written) and then a "
-                         "second timed region of the same K passes runs with split (`split` sub-object), each with its own oracle check")
+                         "against bf16 peak / 3); 'fp32mf' = fp32 with F(2,3) minimal filtering on the stride-1 k = 3 / 7 / 11 layers (fp32 products, ~1.45x "
+                         "fewer; conv1d_f32w.hip); 'both' (default) = the timed region runs with fp32mf (`value`: configs[1]'s fp32 vocoder) and then the same K "
+                         "passes run with the direct fp32 kernels (`fp32_direct` sub-object) and with split (`split`), each with its own oracle check")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (N = 1, default c2 command, "
                                                           "rocprofv3 on PATH) that measure roofline.traffic in this run; fall back to the committed summary")
     ap.add_argument("--pmc-timeout", type=float, default=150.0)
@@ -591,9 +597,12 @@ def main():
         dist.all_reduce(seen)                      # every rank reports in over the data-path backend (RCCL unless one-device test)
         assert int(seen.item()) == world
     log("weights ready; packing")
-    # primary = the precision `value` is measured in (configs[1] as written: fp32 VAE / vocoder); secondary = bf16x3, timed in its own region
-    prim = "fp32" if args.vocoder_precision == "both" else args.vocoder_precision
-    sec = "split" if args.vocoder_precision == "both" else None
+    # primary = the precision `value` is measured in: configs[1]'s fp32 VAE / vocoder - since round 6 with F(2,3) minimal filtering on the
+    # layers it applies to (fp32 products on the f32 MFMA, ~1.45x fewer; held to the same bounds against the reference's outputs as the
+    # direct kernels, tests/test_gpu_path.py).  Secondaries, each timed in its own region of the same K passes and verified the same way:
+    # "fp32" = the direct fp32 kernels (rounds 4-5's `value`), "split" = bf16x3.
+    prim = "fp32mf" if args.vocoder_precision == "both" else args.vocoder_precision
+    secs = ["fp32", "split"] if args.vocoder_precision == "both" else []
     CLS = classes_for(prim)
     ctx = Context(device)
     S = max(1, args.streams)
@@ -610,8 +619,8 @@ def main():
     def make_worker(nclips, clip_base, share=None):
         eng = DiTEngine(ctx, dcfg, sds[0], precision=args.precision, share=share)
         inp = clip_batch(nclips, T_lat, L_CTX, clip0=clip_base, seed=SEED)
-        nets2 = dict(vae=build_vae_decoder(ctx, sds[1], precision=sec), voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=sec),
-                     z0=None, mel0=None, kept={}, wav=None) if sec else None
+        nets2 = {sec: dict(vae=build_vae_decoder(ctx, sds[1], precision=sec), voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=sec),
+                           z0=None, mel0=None, kept={}, wav=None) for sec in secs}
         return dict(eng=eng, vae=build_vae_decoder(ctx, sds[1], precision=prim),
                     voc=build_hifigan(ctx, sds[2], hcfg.as_hparams(), precision=prim), sec=nets2,
                     x0=inp["x_latent"].to(device), t5c=inp["t5_cond"].to(device), t5u=inp["t5_uncond"].to(device),
@@ -627,8 +636,8 @@ def main():
 
     passes_run = [0]
 
-    def one_pass(w, k, second=False):
-        n = w["sec"] if second else w          # the nets and the result slots of this precision
+    def one_pass(w, k, second=None):
+        n = w["sec"][second] if second else w          # the nets and the result slots of this precision (second = a secondary's name)
         if w is workers[0]:
             passes_run[0] += 1
         if long:
@@ -652,7 +661,7 @@ def main():
     cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
     pinned = {}
 
-    def run_worker(w, ks, second=False):
+    def run_worker(w, ks, second=None):
         torch.cuda.set_device(device)           # a new host thread starts on device 0: bind it to this rank's GPU
         si = next((i for i, ww in enumerate(workers) if ww is w), 0)
         import threading
@@ -670,7 +679,7 @@ def main():
             for k in ks:
                 one_pass(w, k, second)
 
-    def run_passes(ks, second=False):
+    def run_passes(ks, second=None):
         import threading
         if S == 1:
             run_worker(workers[0], ks, second)
@@ -701,8 +710,8 @@ def main():
     for wi in range(max(args.warmup, 1)):
         run_passes([-1 - wi])
         torch.cuda.synchronize()
-        if sec:
-            run_passes([-1 - wi], True)
+        for sec in secs:
+            run_passes([-1 - wi], sec)
             torch.cuda.synchronize()
     if not os.environ.get("VB_NO_GRAPH") and not all(w["eng"].graphs() for w in workers):
         # the library captures the sampler loop the SECOND time it sees a call's buffers (the first call warms every kernel's
@@ -711,7 +720,7 @@ def main():
         run_passes([-50])
         torch.cuda.synchronize()
     assert all(torch.isfinite(w["wav"]).all() for w in workers)
-    assert not sec or all(torch.isfinite(w["sec"]["wav"]).all() for w in workers)
+    assert all(torch.isfinite(w["sec"][sec]["wav"]).all() for w in workers for sec in secs)
 
     # ---- every kernel class ALONE on the GPU: one stream, the whole batch of B clips, every 7th launch of each class bracketed by
     # HIP events on the launch stream.  This is the kernel-quality figure (roofline.frac): in the timed region below two
@@ -724,7 +733,7 @@ def main():
     # rocprofv3 to 2 %.  ms_per_pass and the algorithmic work per launch are totals over all launches, not a sample mean scaled up
     # (rounds 3-4 timed every 7th launch: 181 GFLOP per pair launch where the true mean is 166).
     EVERY, EVERY_OTHER, PROF_PASSES = 7, 2, 14
-    table, table_sec, dominant = [], [], 0
+    table, table_sec, dominant = [], {}, 0
     GROUPS = {"bf16 MFMA GEMMs of the DiT (projections, routed + band experts)": (0,), "bf16 flash attention (self + T5 cross)": (1,),
               f"VAE + vocoder convolutions in {'exact fp32 (v_mfma_f32_32x32x2_f32)' if prim == 'fp32' else 'fp32 with F(2,3) minimal filtering (v_mfma_f32_32x32x2_f32)' if prim == 'fp32mf' else 'split-bf16 (bf16x3)'}: implicit-GEMM conv1d + "
               "fused HiFi-GAN ResBlock pairs": (2, 3)}
@@ -753,7 +762,7 @@ def main():
                          "frac_of_hbm_peak": tbs / HBM_PEAK_TBS})
         return rows
 
-    def profiled_passes(w, seeds0, mask, classes, secondary=False):
+    def profiled_passes(w, seeds0, mask, classes, secondary=None):
         """PROF_PASSES one-stream passes with the rotating phases; returns {cls: totals}"""
         tot = {c: [0.0, 0.0, 0.0, 0, 0] for c in classes}
         for i in range(PROF_PASSES):
@@ -795,11 +804,11 @@ def main():
         dominant = max(per, key=lambda c: per_pass(c)[0] if per[c][4] else 0.0)
         if dom_group:
             dominant = max(dom_group["class_ids"], key=lambda c: per_pass(c)[0] if per[c][4] else 0.0)
-        if sec:
-            # the convolution classes once more with the bf16x3 nets (classes 2 and 3 only: the DiT classes do not change)
-            run_worker(w, [-110], True)
+        for sec in secs:
+            # the convolution classes once more with each secondary's nets (classes 2 and 3 only: the DiT classes do not change)
+            run_worker(w, [-110], sec)
             torch.cuda.synchronize()
-            table_sec = class_rows(profiled_passes(w, -131, 0xC, [2, 3], True), classes_for(sec), PROF_PASSES)
+            table_sec[sec] = class_rows(profiled_passes(w, -131, 0xC, [2, 3], sec), classes_for(sec), PROF_PASSES)
         if S > 1:
             del w
             torch.cuda.empty_cache()
@@ -828,24 +837,24 @@ def main():
     log(f"timed region: {elapsed:.3f}s")
     ms, fl, by, n, nt = read_prof(dominant) if args.profile_timed else (0.0, 0.0, 0.0, 0, 0)
     L.check(lib.vb_prof_enable(0), "prof")
-    elapsed_sec, per_rank_ms_sec = None, None
-    if sec:
-        # the same K passes with the bf16x3 VAE / vocoder, timed the same way (barrier + synchronize on both sides, max over ranks)
+    elapsed_sec, per_rank_ms_sec = {}, {}
+    for sec in secs:
+        # the same K passes with this secondary's VAE / vocoder, timed the same way (barrier + synchronize on both sides, max over ranks)
         barrier()
         t0 = time.perf_counter()
-        run_passes(list(range(args.steps)), True)
+        run_passes(list(range(args.steps)), sec)
         barrier()
-        elapsed_sec = time.perf_counter() - t0
-        per_rank_ms_sec = [1e3 * elapsed_sec / args.steps]
+        elapsed_sec[sec] = time.perf_counter() - t0
+        per_rank_ms_sec[sec] = [1e3 * elapsed_sec[sec] / args.steps]
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([elapsed_sec], device=device, dtype=torch.float64)
+            t = torch.tensor([elapsed_sec[sec]], device=device, dtype=torch.float64)
             allt = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
-            per_rank_ms_sec = [1e3 * float(v.item()) / args.steps for v in allt]
+            per_rank_ms_sec[sec] = [1e3 * float(v.item()) / args.steps for v in allt]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed_sec = float(t.item())
-        log(f"second timed region ({sec} VAE / vocoder): {elapsed_sec:.3f}s")
+            elapsed_sec[sec] = float(t.item())
+        log(f"secondary timed region ({sec} VAE / vocoder): {elapsed_sec[sec]:.3f}s")
 
     def verify(slots, label, with_flips):
         """everything a timed region produced that an oracle fixture covers: clip 0 of pass 0 against the workload's digest; on the default
@@ -903,13 +912,13 @@ def main():
             (f"; routing flips per block {par['routing_flips']['per_block']} of {par['routing_flips']['decisions_per_block']}" if with_flips else ""))
         return par
 
-    parity, parity_sec = None, None
+    parity, parity_sec = None, {}
     if rank == 0 and not args.no_parity_check and args.flow_steps == 50 and args.scale == 3.0 and args.precision == "bf16" and args.steps >= 1:
         # one oracle fixture per workload shape: 20 s clips with 4 / 8 experts (clip 0 does not depend on the batch it rides in), and
         # the 120 s long-form clip whose window rows / noise keys depend on the batch (4).  A failure anywhere fails the run (exit code 3).
         parity = verify(workers, f"{prim} VAE / vocoder", True)
-        if sec:
-            parity_sec = verify([w["sec"] for w in workers], f"{sec} VAE / vocoder", False)
+        for sec in secs:
+            parity_sec[sec] = verify([w["sec"][sec] for w in workers], f"{sec} VAE / vocoder", False)
 
     if rank == 0:
         name, bound, peak = CLS[dominant]
@@ -964,9 +973,10 @@ def main():
                                         ("split-bf16 (bf16x3 products, fp32 I/O and accumulation, <= 3e-5 of exact fp32; `--vocoder-precision fp32` "
                                          "runs the literal fp32 kernels)" if prim == "split" else
                                          "fp32 on the f32 MFMA with F(2,3) minimal filtering (fp32 products, ~1.45x fewer on the layers it applies to; "
-                                         "<= 2e-6 of the direct fp32 kernels)" if prim == "fp32mf" else
+                                         "<= 2e-6 of the direct fp32 kernels)" + ("; the same K passes with the direct fp32 kernels and with the bf16x3 "
+                                         "VAE / vocoder are timed in their own regions: `fp32_direct`, `split`" if secs else "") if prim == "fp32mf" else
                                          "exact fp32 (f32 MFMA, configs[1] as written)" + ("; the same K passes with the bf16x3 VAE / vocoder are timed in a "
-                                                                                            "second region and reported under `split`" if sec else "")),
+                                                                                            "second region and reported under `split`" if secs else "")),
                        "vocoder_precision": prim,
                        "baseline_config": {"c2": "configs[1]", "c3": "configs[2]", "c5": "configs[4]"}[args.workload],
                        "clips_per_gpu": B, "clip_seconds": clip_seconds, "flow_steps": args.flow_steps, "precision": args.precision, "experts": args.experts,
@@ -1008,13 +1018,23 @@ def main():
                                "ideal_ms": g["ideal_ms_per_pass_at_mfma_peak"], "measured_ms_alone": g["ms_per_pass"]} for g in groups],
                 "how": "sum over kernel groups of (algorithmic flops per pass / dense MFMA peak of the group's arithmetic) / ms_per_step; flops = the "
                        "library's per-launch algorithmic counts (DESIGN.md section 4) summed over every launch of a pass"}
-        if sec:
-            out["split"] = {
-                "what": "the same workload and the same K passes with the VAE / vocoder on split-bf16 (bf16x3: every product as hi*hi + lo*hi + hi*lo on "
-                        "the bf16 MFMA pipe, fp32 I/O and accumulation, <= 3e-5 of exact fp32) - narrower than the fp32 arithmetic configs[1] names, "
-                        "so it is reported beside `value`, not as it",
-                "value": total_mel_s / elapsed_sec, "unit": "mel-s/s", "ms_per_step": 1e3 * elapsed_sec / args.steps, "steps": args.steps,
-                "per_rank_ms": per_rank_ms_sec, "vocoder_precision": sec, "parity_check": parity_sec, "classes": table_sec}
+        what = {"split": "the same workload and the same K passes with the VAE / vocoder on split-bf16 (bf16x3: every product as hi*hi + lo*hi + hi*lo on "
+                         "the bf16 MFMA pipe, fp32 I/O and accumulation, <= 3e-5 of exact fp32) - narrower than the fp32 arithmetic configs[1] names, "
+                         "so it is reported beside `value`, not as it",
+                "fp32": "the same workload and the same K passes with the DIRECT fp32 convolution kernels everywhere (no minimal filtering; the 64-channel "
+                        "ResBlock pairs fused): what `value` measured in rounds 4-5"}
+        for sec in secs:
+            out["fp32_direct" if sec == "fp32" else sec] = {
+                "what": what[sec], "value": total_mel_s / elapsed_sec[sec], "unit": "mel-s/s", "ms_per_step": 1e3 * elapsed_sec[sec] / args.steps,
+                "steps": args.steps, "per_rank_ms": per_rank_ms_sec[sec], "vocoder_precision": sec, "parity_check": parity_sec.get(sec),
+                "classes": table_sec.get(sec, [])}
+        if prim == "fp32mf" and dom_group and table_sec.get("fp32"):
+            # direct-convolution-equivalent throughput of the dominant group: the flops the direct kernels execute for the same layers (the
+            # `fp32` secondary's class table) over this run's group time; `frac` above stays on the flops the minimal-filtering kernels execute
+            dgf = sum(r["algorithmic_gflop_per_pass"] for r in table_sec["fp32"])
+            out["roofline"]["direct_equivalent"] = {"achieved": dgf / dom_group["ms_per_pass"], "unit": "TFLOP/s",
+                                                    "frac": dgf / dom_group["ms_per_pass"] / dom_group["mfma_peak_tflops"],
+                                                    "direct_gflop_per_pass": dgf, "executed_gflop_per_pass": dom_group["algorithmic_gflop_per_pass"]}
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
@@ -1028,7 +1048,7 @@ def main():
             detail_path = None
         sys.stderr.flush()
         print(compact_line(out, detail_path), flush=True)
-        if (parity is not None and parity.get("ok") is False) or (parity_sec is not None and parity_sec.get("ok") is False):
+        if (parity is not None and parity.get("ok") is False) or any(v is not None and v.get("ok") is False for v in parity_sec.values()):
             log("PARITY CHECK FAILED")
     if rank == 0:
         log(f"PASSES_RUN={passes_run[0]}")      # (read back by the PMC child-run parser: counter sums -> bytes per pass)
@@ -1043,7 +1063,7 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and ((parity is not None and parity.get("ok") is False) or (parity_sec is not None and parity_sec.get("ok") is False)):
+    if rank == 0 and ((parity is not None and parity.get("ok") is False) or any(v is not None and v.get("ok") is False for v in parity_sec.values())):
         sys.exit(3)
 
 

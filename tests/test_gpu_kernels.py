@@ -424,7 +424,7 @@ def test_fp32_dma_conv_is_bit_identical_to_register_staged(lib, monkeypatch, B, 
 MF_CASES = [(2, 128, 1000, 128, 3, 1, 1, True), (1, 256, 752, 256, 3, 3, 1, False), (2, 128, 488, 128, 3, 5, 1, True),
             (1, 128, 1204, 128, 7, 1, 1, True), (2, 256, 360, 256, 7, 3, 1, False), (1, 128, 600, 128, 7, 5, 0, True),
             (1, 256, 724, 256, 11, 1, 1, True), (2, 128, 500, 128, 11, 3, 1, False), (1, 128, 1000, 128, 11, 5, 1, True),
-            (1, 64, 2000, 128, 11, 5, 1, True), (1, 384, 304, 192, 3, 1, 0, True), (2, 96, 244, 160, 5, 2, 1, False), (1, 128, 120, 128, 7, 3, 1, True)]
+            (1, 64, 2000, 128, 11, 5, 1, True), (1, 64, 2000, 64, 11, 5, 1, True), (2, 64, 1028, 64, 7, 3, 1, True), (1, 64, 520, 64, 3, 1, 1, False), (1, 384, 304, 192, 3, 1, 0, True), (2, 96, 244, 160, 5, 2, 1, False), (1, 128, 120, 128, 7, 3, 1, True)]
 
 
 @pytest.mark.parametrize("B,Ci,T,Co,k,dil,act,res", MF_CASES)
@@ -460,7 +460,7 @@ def test_fp32_minimal_filtering_conv_matches_the_direct_kernel(lib, B, Ci, T, Co
 
 
 def test_fp32_minimal_filtering_switches(lib, monkeypatch):
-    """VB_MF_OCC=2 runs the same kernel built for two workgroups per CU: same bits as the three-per-CU build.  VB_CONV_MF_OFF=1 ignores
+    """VB_MF_OCC=3 runs the same kernel built for three workgroups per CU: same bits as the default two-per-CU build.  VB_CONV_MF_OFF=1 ignores
     the minimal-filtering weights: the call is the direct fp32 kernel, bit for bit."""
     B, C, T, k, dil = 2, 128, 1000, 11, 3
     x, w, b = dev(rnd((B, C, T), "sx2")), rnd((C, C, k), "sw2", 1.0 / (C * k) ** 0.5), dev(rnd((C,), "sb2"))
@@ -478,7 +478,7 @@ def test_fp32_minimal_filtering_switches(lib, monkeypatch):
     base = mf()
     assert not torch.equal(base, direct) and float((base - direct).abs().max()) < 4e-6 * float(direct.abs().max())
     try:
-        monkeypatch.setenv("VB_MF_OCC", "2")
+        monkeypatch.setenv("VB_MF_OCC", "3")
         lib.vb_tune_reload()
         assert torch.equal(mf(), base)
         monkeypatch.delenv("VB_MF_OCC")

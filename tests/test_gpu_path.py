@@ -682,6 +682,17 @@ def test_fullsize_reference_digests(ctx, engines):
     wav32 = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision="fp32").run(mel32)
     torch.cuda.synchronize()
     check_digest(wav32, g, "voc_wav_", 2e-6)       # measured: 1.2e-6 / 1.7e-8 (split: 7.5e-6 / 1.4e-6)
+    # fp32 with F(2,3) minimal filtering (round 6, conv1d_f32w.hip: the VAE's 3-tap layers, the generator's 64 / 128 / 256-channel ResBlock
+    # convolutions - its 64-channel pairs run as two minimal-filtering launches, the 32-channel pairs stay fused and direct): fp32 products,
+    # ~1.45x fewer; held to the SAME bounds against the reference's own outputs as the direct fp32 kernels
+    melmf = build_vae_decoder(ctx, synth.make_state_dict(synth.vae_decoder_shapes(vcfg), SEED + 1), precision="fp32mf").run(z)
+    check_digest(melmf, g, "vae_mel_", 2e-6)
+    wavmf = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision="fp32mf").run(melmf)
+    torch.cuda.synchronize()
+    check_digest(wavmf, g, "voc_wav_", 2e-6)
+    assert not torch.equal(wavmf, wav32)                 # (the mode really took the other kernels)
+    print(f"fp32mf vs fp32 direct at full size: mel max|d| {float((melmf - mel32).abs().max()):.3e} of {float(mel32.abs().max()):.3f}, "
+          f"wav max|d| {float((wavmf - wav32).abs().max()):.3e} of {float(wav32.abs().max()):.3f}")
 
 
 def test_t5_encoder_vs_transformers_golden_and_oracle(ctx):

@@ -81,7 +81,7 @@ struct VbTune {
     bool conv_direct_epi = false, gate_unfolded = false, stem_f32 = false, band_unfused = false, score_fused = false, no_graph = false;
     int w2_pair = 1;
     bool qkv_p16_off = false, no_xcd_groups = false, qkv_vt16_off = false, rmsnorm_generic = false;
-    int wide_resid = 1, big_tile_min_k = 384, conv_mf_occ = 3;
+    int wide_resid = 1, big_tile_min_k = 384, conv_mf_occ = 2;
     bool proj_in_conv = false, conv_gemm_off = false, final_gemm = false, router_generic = false, band_epi_old = false;
     bool conv_f32_old = false, gemm_p8_off = false, conv_f32_rt_taps = false, bucket_count_launch = false, euler_launch = false, conv_mf_off = false;
 };

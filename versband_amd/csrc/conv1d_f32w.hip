@@ -74,11 +74,12 @@ __host__ __device__ constexpr int mf_ntaps(int K) { return 4 * (K / 3) + (K % 3 
 #define MFMA_ACC(c, a, b) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
 #endif
 
-template <int K, int OCC>
+// WN = waves along time (2: tile 128 co x 4 VW positions; 4: 64 co x 8 VW positions - the 64-channel layers)
+template <int K, int OCC, int WN>
 __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) {
-    constexpr int WN = 2, TM = 2, NSW = 3;
+    constexpr int TM = 2, NSW = 3, WM = 4 / WN;
     constexpr int P = mf_ntaps(K);
-    constexpr int CO_TILE = 128, XP = 192, NP = XP / 64;
+    constexpr int CO_TILE = WM * TM * 32, XP = WN * 64 + 64, NP = XP / 64;
     constexpr int XST = GK * XP, WT = GK * CO_TILE;
     constexpr int NWI = CO_TILE / 16, WPW = NWI / 4, XPW = NP;
     static_assert(P >= NSW - 1, "a step issues the tile NSW - 1 ahead: it lies in this chunk or the next one");
@@ -335,23 +336,24 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
     }
 }
 
-template <int K, int OCC>
+template <int K, int OCC, int WN>
 static void launch_w(ConvDev& d, int B, hipStream_t st) {
-    constexpr int BYTES = (2 * GK * 192 + 3 * GK * 128) * (int)sizeof(float);
-    const int T_TILE = 4 * ((32 / d.dil) * d.dil);
-    d.g_nt = cdiv(d.T_out, T_TILE); d.g_nco = cdiv(d.Co, 128);
+    constexpr int CO_TILE = (4 / WN) * 64, XP = WN * 64 + 64;
+    constexpr int BYTES = (2 * GK * XP + 3 * GK * CO_TILE) * (int)sizeof(float);
+    const int T_TILE = WN * 2 * ((32 / d.dil) * d.dil);
+    d.g_nt = cdiv(d.T_out, T_TILE); d.g_nco = cdiv(d.Co, CO_TILE);
     d.g_ntb = d.g_nt * B; d.g_tbx = cdiv(d.g_ntb, 8);
     static OnceFlags once;
-    vb_set_max_lds_once(once, (const void*)conv1d_f32w_kernel<K, OCC>, BYTES);
-    hipLaunchKernelGGL((conv1d_f32w_kernel<K, OCC>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
+    vb_set_max_lds_once(once, (const void*)conv1d_f32w_kernel<K, OCC, WN>, BYTES);
+    hipLaunchKernelGGL((conv1d_f32w_kernel<K, OCC, WN>), dim3(8 * d.g_tbx * d.g_nco), dim3(256), BYTES, st, d);
 }
-template <int OCC>
+template <int OCC, int WN>
 static void launch_w_k(ConvDev& d, int B, hipStream_t st) {
     switch (d.ntaps) {
-        case 3: launch_w<3, OCC>(d, B, st); break;
-        case 5: launch_w<5, OCC>(d, B, st); break;
-        case 7: launch_w<7, OCC>(d, B, st); break;
-        default: launch_w<11, OCC>(d, B, st); break;
+        case 3: launch_w<3, OCC, WN>(d, B, st); break;
+        case 5: launch_w<5, OCC, WN>(d, B, st); break;
+        case 7: launch_w<7, OCC, WN>(d, B, st); break;
+        default: launch_w<11, OCC, WN>(d, B, st); break;
     }
 }
 
@@ -359,8 +361,12 @@ bool conv1d_f32w_supported(int ksize, int dil) { return (ksize == 3 || ksize == 
 int conv1d_f32w_pseudo_taps(int ksize) { return mf_ntaps(ksize); }
 
 // the caller (launch_conv1d) has checked the conditions it shares with conv1d_f32g_kernel.  Two builds of the same code: <= 168 VGPRs (three
-// workgroups per CU, 49 KB of LDS each) and <= 256 (two); VB_MF_OCC=2 selects the second (A/B knob)
+// workgroups per CU, 49 KB of LDS each) and <= 256 (two).  Two per CU measured 1 % faster end to end (1174 against 1163 mel-s/s, same box):
+// the default; VB_MF_OCC=3 selects the other (A/B knob)
 void launch_conv1d_f32w(ConvDev& d, int B, hipStream_t st) {
-    if (vb_tune().conv_mf_occ == 2) launch_w_k<2>(d, B, st);
-    else launch_w_k<3>(d, B, st);
+    // 64 co x 8 VW tiles where a 128-channel tile would be half empty (Co <= 64) or leave a half-empty last tile (Co % 128 in (0, 64])
+    const bool narrow = d.Co <= 64 || (d.Co % 128 != 0 && d.Co % 128 <= 64 && d.Co < 256);
+    if (narrow) launch_w_k<2, 4>(d, B, st);          // (five window pieces per wave: 177 VGPRs - the two-per-CU build only)
+    else if (vb_tune().conv_mf_occ == 3) launch_w_k<3, 2>(d, B, st);
+    else launch_w_k<2, 2>(d, B, st);
 }

@@ -49,7 +49,7 @@ static void tune_load() {
     t.bucket_count_launch = getenv("VB_BUCKET_COUNT_LAUNCH") != nullptr;
     t.euler_launch = getenv("VB_EULER_LAUNCH") != nullptr;
     t.conv_f32_rt_taps = getenv("VB_CONV_F32_RT_TAPS") != nullptr;
-    t.conv_mf_off = getenv("VB_CONV_MF_OFF") != nullptr; t.conv_mf_occ = env_int("VB_MF_OCC", 3);        // minimal-filtering weights ignored: the direct fp32 kernels (A/B)
+    t.conv_mf_off = getenv("VB_CONV_MF_OFF") != nullptr; t.conv_mf_occ = env_int("VB_MF_OCC", 2);        // minimal-filtering weights ignored: the direct fp32 kernels (A/B)
     t.no_graph = getenv("VB_NO_GRAPH") != nullptr;
 #ifdef VB_EXPERIMENTS
     // experiments build only (VB_BUILD_EXPERIMENTS=1 python -m versband_amd.build): ablations and the measured-slower kernels

@@ -360,7 +360,7 @@ class NetBuilder:
             w_x3 = planes.data_ptr()
         w_mf = None
         if (self.mf and w is not None and w_buf == -1 and tr_stride == 1 and in_stride == 1 and not upsample2 and not out_transposed and
-                k in (3, 5, 7, 11) and (k - 1) * dil <= 60 and dil <= 8 and Ci % 16 == 0 and Co % 4 == 0 and Co >= 128 and
+                k in (3, 5, 7, 11) and (k - 1) * dil <= 60 and dil <= 8 and Ci % 16 == 0 and Co % 4 == 0 and Co >= 64 and
                 in_act in (L.ACT_NONE, L.ACT_LRELU) and w.shape == (k, Ci, Co)):
             w_mf = self._t(pack.pack_conv_mf(w.permute(2, 1, 0)))          # (w arrives packed [k][Ci][Co])
         op = L.NetOp(kind=L.OP_CONV, x=x, out=out, res=res, stats=stats, w_buf=w_buf, w=self._t(w), bias=self._t(bias), w2_x3=w_mf,
@@ -615,7 +615,9 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
     driven by the vocoder's config.yaml keys."""
     nb = NetBuilder(ctx.device, precision)
     # exact-fp32 mode: channel counts whose ResBlock1 pairs run fused (respair_f32_kernel); VB_FP32_PAIRS="32,64" / "" for A/B runs
-    fp32_pairs = tuple(int(v) for v in os.environ.get("VB_FP32_PAIRS", "32,64").split(",") if v.strip())
+    # (fp32mf: the 64-channel pairs run faster as two minimal-filtering launches than fused and direct - 1201 -> 1232 mel-s/s on one box,
+    #  profiles/r06_mf_pairs_ab.txt - so only the 32-channel pairs stay fused there)
+    fp32_pairs = tuple(int(v) for v in os.environ.get("VB_FP32_PAIRS", "32" if precision == "fp32mf" else "32,64").split(",") if v.strip())
 
     def wt(name):
         if name + ".weight" in sd:
