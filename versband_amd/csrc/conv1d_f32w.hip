@@ -77,16 +77,19 @@ __host__ __device__ constexpr int mf_ntaps(int K) { return 4 * (K / 3) + (K % 3 
 // WN = waves along time (2: tile 128 co x 4 VW positions; 4: 64 co x 8 VW positions - the 64-channel layers)
 template <int K, int OCC, int WN>
 __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) {
-    constexpr int TM = 2, NSW = 3, WM = 4 / WN;
+    // ring depth = conv1d_f32g_kernel's: two window stages, three weight stages (49 KB; 60 KB on the 64-channel tile).  (Round 6, measured and not
+    // adopted: five weight stages in the two-per-CU build - vmcnt retires in order, so every load's lead, the window's too, is NSW - 1 ring steps -
+    // no faster on the layer shapes and 1.5 % slower to equal end to end: 1215 / 1193 against 1199 / 1205 mel-s/s, profiles/r06_mf_ring_depth.txt.)
+    constexpr int TM = 2, WM = 4 / WN, NXS = 2, NSW = 3;
     constexpr int P = mf_ntaps(K);
     constexpr int CO_TILE = WM * TM * 32, XP = WN * 64 + 64, NP = XP / 64;
     constexpr int XST = GK * XP, WT = GK * CO_TILE;
     constexpr int NWI = CO_TILE / 16, WPW = NWI / 4, XPW = NP;
     static_assert(P >= NSW - 1, "a step issues the tile NSW - 1 ahead: it lies in this chunk or the next one");
-    static_assert((2 * XST + NSW * WT) >= 4 * 32 * MF_PITCH, "the staging patches must fit in the rings");
+    static_assert((NXS * XST + NSW * WT) >= 4 * 32 * MF_PITCH, "the staging patches must fit in the rings");
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     float* lx = w_lds;
-    float* lw = w_lds + 2 * XST;
+    float* lw = w_lds + NXS * XST;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,16 +132,16 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
         xsrc[i] = ci * p.T_in + (ok ? idx : 0);
         xoob |= ok ? 0u : (1u << i);
     }
-    auto issue_x = [&](int ch) {
+    auto issue_x = [&](int ch, int stage) {
         const float* src = xbase + (int64_t)ch * GK * p.T_in;
-        float* dst = lx + (ch & 1) * XST;
+        float* dst = lx + stage * XST;
 #pragma unroll
         for (int i = 0; i < XPW; ++i)
             __builtin_amdgcn_global_load_lds((w_glb_ptr_t)(src + xsrc[i]), (w_lds_ptr_t)(dst + (wave * XPW + i) * 256), 16, 0, 0);
     };
     const bool act = p.in_act == ACT_LRELU;
-    auto fix_x = [&](int ch) {        // zero padding + LeakyReLU in place, by the lanes whose own DMA brought the quads
-        const unsigned a0 = lds_u32(lx + (ch & 1) * XST + wave * XPW * 256 + lane * 4);
+    auto fix_x = [&](int stage) {     // zero padding + LeakyReLU in place, by the lanes whose own DMA brought the quads
+        const unsigned a0 = lds_u32(lx + stage * XST + wave * XPW * 256 + lane * 4);
         lds_u32x4 v[XPW];
         const lds_u32x4 zero = {0u, 0u, 0u, 0u};
         if (act) {
@@ -178,7 +181,8 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
             for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
 
     const int nchunks = p.Ci / GK;
-    issue_x(0);
+#pragma unroll
+    for (int c = 0; c < NXS - 1; ++c) issue_x(c < nchunks ? c : 0, c);      // windows first: they retire first
 #pragma unroll
     for (int t = 0; t < NSW - 1; ++t) issue_w(0, t, t);       // P >= NSW - 1: the first tiles all lie in chunk 0
 
@@ -199,9 +203,11 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
     // window and the first NSW - 1 tiles of the "next" chunk, re-read from chunk 0 into slots nobody reads again - so that every counted
     // wait sees the same pieces in flight; they are drained in front of the epilogue.
     int slot = 0, nslot = NSW - 1;
+    int xs = 0, xsn = NXS - 1;            // window stage of chunk ch; stage the window issued at this chunk's first step goes to
     for (int ch = 0; ch < nchunks; ++ch) {
-        const unsigned xa_ch = xa0 + (ch & 1) * (XST * 4);
-        const int chn = ch + 1 < nchunks ? ch + 1 : 0;          // source of the loads a step issues for the next chunk
+        const unsigned xa_ch = xa0 + xs * (XST * 4);
+        const int chn = ch + 1 < nchunks ? ch + 1 : 0;          // source of the weight tiles a step issues for the next chunk
+        const int chx = ch + NXS - 1 < nchunks ? ch + NXS - 1 : 0;      // ... and of the window it issues (NXS - 1 chunks ahead)
         w_static_for<0, P>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             constexpr MfTap TP = mf_tap(K, J);
@@ -209,14 +215,14 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
             constexpr int AH = NSW - 2;                                   // younger weight tiles that may fly
             if constexpr (J == 0) {
                 w_wait_vmcnt<AH * WPW>();
-                if (act || xoob) { fix_x(ch); LDS_WAIT(0); }
+                if (act || xoob) { fix_x(xs); LDS_WAIT(0); }
             } else {
                 w_wait_vmcnt<AH * WPW + (J <= NSW - 2 ? XPW : 0)>();
             }
             __builtin_amdgcn_s_barrier();
-            if constexpr (J == 0) {       // window ch + 1 -> the other stage
-                const float* src = xbase + (int64_t)chn * GK * p.T_in;
-                float* dst = lx + ((ch + 1) & 1) * XST;
+            if constexpr (J == 0) {       // window ch + NXS - 1 -> the stage chunk ch - 1 has just left
+                const float* src = xbase + (int64_t)chx * GK * p.T_in;
+                float* dst = lx + xsn * XST;
 #pragma unroll
                 for (int i = 0; i < XPW; ++i)
                     __builtin_amdgcn_global_load_lds((w_glb_ptr_t)(src + xsrc[i]), (w_lds_ptr_t)(dst + (wave * XPW + i) * 256), 16, 0, 0);
@@ -267,6 +273,8 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
             if (++slot == NSW) slot = 0;
             if (++nslot == NSW) nslot = 0;
         });
+        if (++xs == NXS) xs = 0;
+        if (++xsn == NXS) xsn = 0;
     }
     w_wait_vmcnt<0>();                   // the loads the last chunk issued for a chunk that does not exist
     {
@@ -339,7 +347,8 @@ __global__ void __launch_bounds__(256, OCC) conv1d_f32w_kernel(const ConvDev p) 
 template <int K, int OCC, int WN>
 static void launch_w(ConvDev& d, int B, hipStream_t st) {
     constexpr int CO_TILE = (4 / WN) * 64, XP = WN * 64 + 64;
-    constexpr int BYTES = (2 * GK * XP + 3 * GK * CO_TILE) * (int)sizeof(float);
+    constexpr int NXS = 2, NSW = 3;      // (the kernel's ring depths)
+    constexpr int BYTES = (NXS * GK * XP + NSW * GK * CO_TILE) * (int)sizeof(float);
     const int T_TILE = WN * 2 * ((32 / d.dil) * d.dil);
     d.g_nt = cdiv(d.T_out, T_TILE); d.g_nco = cdiv(d.Co, CO_TILE);
     d.g_ntb = d.g_nt * B; d.g_tbx = cdiv(d.g_ntb, 8);
