@@ -51,7 +51,35 @@ def device_noise(seed, clip, nfe, branch, E=E, T=T):
 def main_long():
     """bench.py --workload c5: 4 clips of 120 s (T = 4500) per GPU; versband_amd.longform.sample_long turns the windows into batch rows
     (row = window * B + clip, noise key = clip_base * n_windows + row) and cross-fades them.  Clip 0 = rows 0, 4, 8, 12."""
-    from versband_amd.longform import crossfade_windows, plan_windows
+    # (the window plan and the cross-fade are restated HERE: the oracle must not lean on the product package for the thing it checks)
+    def plan_windows(T, window, overlap):
+        """[(start, length)]: windows of `window` tokens hopping by window - overlap, the last one aligned to the end of the clip"""
+        if T <= window:
+            return [(0, T)]
+        out, s0 = [], 0
+        while s0 + window < T:
+            out.append((s0, window))
+            s0 += window - overlap
+        out.append((T - window, window))
+        return out
+
+    def crossfade_windows(parts, plan, T):
+        """linear ramps over every overlap, weights normalised to one"""
+        acc = torch.zeros(parts[0].shape[0], parts[0].shape[1], T, dtype=parts[0].dtype)
+        wsum = torch.zeros(T, dtype=parts[0].dtype)
+        for i, ((s0, n), part) in enumerate(zip(plan, parts)):
+            w = torch.ones(n, dtype=part.dtype)
+            if i > 0:
+                ov = plan[i - 1][0] + plan[i - 1][1] - s0
+                if ov > 0:
+                    w[:ov] = torch.linspace(0, 1, ov + 2, dtype=part.dtype)[1:-1]
+            if i + 1 < len(plan):
+                ov = s0 + n - plan[i + 1][0]
+                if ov > 0:
+                    w[n - ov:] = torch.minimum(w[n - ov:], torch.linspace(1, 0, ov + 2, dtype=part.dtype)[1:-1])
+            acc[:, :, s0:s0 + n] += part * w
+            wsum[s0:s0 + n] += w
+        return acc / wsum
     B, TL, WIN, OV = 4, 4500, 1500, 128
     torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
     dcfg, vcfg = synth.DiTConfig(), synth.VAEConfig()

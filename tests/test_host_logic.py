@@ -318,7 +318,9 @@ def test_bench_line_is_one_short_json_line():
                          "per_rank_ms": [139.391012518] * 8})
     big["config"]["workload"] = big["config"]["workload"] * 3
     big["cpu_baseline"]["sample"] = big["cpu_baseline"]["sample"] * 5
-    for src in (full, big):
+    r06 = json.load(open(os.path.join(ROOT, "profiles", "r06_f_bench_detail.json")))     # three timed regions: value (fp32mf), fp32_direct, split
+    assert "fp32_direct" in r06 and "direct_equivalent" in r06["roofline"]
+    for src in (full, big, r06):
         s = bench.compact_line(src, "/tmp/bench_detail.json")
         assert len(s) <= bench.LINE_MAX == 4096 and "\n" not in s and s.startswith("{") and s.endswith("}")
         d = json.loads(s)
@@ -335,6 +337,9 @@ def test_bench_line_is_one_short_json_line():
         cb = d["cpu_baseline"]
         assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "mel-s/s" and cb["sample"]
         assert d["parity_check"]["ok"] is True and d["parity_check"]["worst"]["latent_rel_l2"] < 1e-3
+    d6 = json.loads(bench.compact_line(r06, None))
+    assert d6["fp32_direct"]["parity_ok"] is True and d6["split"]["parity_ok"] is True and d6["value"] > d6["fp32_direct"]["value"]
+    assert d6["roofline"]["direct_equivalent"]["frac"] > d6["roofline"]["frac"] and d6["config"]["vocoder_precision"] == "fp32mf"
     d8 = json.loads(bench.compact_line(big, None))
     assert d8["ranks"]["backend"] == "nccl (RCCL)" and len(d8["ranks"]["per_rank_ms"]) == 8 and d8["detail"] is None
     # a result without the optional blocks (--no-parity-check --no-cpu-baseline --no-isolated) still makes a line
@@ -404,3 +409,21 @@ def test_reference_yaml_loads_unchanged():
     for k in ("unet_config", "cond_stage_config"):
         assert cfg.model.params[k] == ours.model.params[k]
     assert cfg.model.params.first_stage_config.params.ddconfig == ours.model.params.first_stage_config.params.ddconfig
+
+
+def test_oracle_long_form_restatement_matches_the_product_plan():
+    """oracle/gen_bench_digest.py --long restates the window plan and the cross-fade itself (round 6: it imported them from the product
+    package); the two restatements must agree - on the plan exactly, on the blend bit for bit."""
+    import textwrap
+    from versband_amd import longform
+    src = open(os.path.join(ROOT, "oracle", "gen_bench_digest.py")).read()
+    assert "from versband_amd.longform" not in src and "import versband_amd.longform" not in src
+    i, j = src.index("    def plan_windows(T, window, overlap):"), src.index("    B, TL, WIN, OV = 4, 4500, 1500, 128")
+    ns = {"torch": torch}
+    exec(textwrap.dedent(src[i:j]), ns)
+    for T, w, o in ((4500, 1500, 128), (1000, 1500, 128), (3000, 1500, 128), (1501, 1500, 128), (2872, 1500, 128), (6000, 1500, 0)):
+        assert ns["plan_windows"](T, w, o) == longform.plan_windows(T, w, o)
+    plan = longform.plan_windows(4500, 1500, 128)
+    g = torch.Generator().manual_seed(3)
+    parts = [torch.randn(2, 3, 1500, generator=g) for _ in plan]
+    assert torch.equal(ns["crossfade_windows"](parts, plan, 4500), longform.crossfade_windows(parts, plan, 4500))

@@ -932,6 +932,10 @@ static int sample_steps(vb_ctx* ctx, float* x, const void* cond, int B, int n_br
     }
     // FinalLayer, CFG combination, Euler update and the step counter's advance as ONE launch per step (round 5; VB_EULER_LAUNCH=1 keeps the three
     // launches: same arithmetic, bit-identical)
+    // (the ping-pong count tables stay right only while EVERY block evaluation runs router(table e & 1) -> place(clears table
+    //  (e + 1) & 1) with one G / N / knob state - true here because fused_router / w2_pair are uniform over the blocks and the clear above is
+    //  inside the captured graph; a per-block switch would need its own clear.  The device step counter s.step ends a call at n_steps with the
+    //  fused Euler launch and at n_steps - 1 with the separate launches; nothing reads it after the call, launch_step_ctl resets it at k == 0.)
     const bool fuse = euler_fusable(ctx, n_branch);
     for (int k = 0; k < n_steps; ++k) {
         RoctxRange rs("euler_step");
