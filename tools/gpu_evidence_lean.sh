@@ -1,5 +1,5 @@
 #!/bin/bash
-# Lean evidence run of a round (about ten GPU-minutes): whole GPU suite, smoke, the default bench line (fp32 `value` + bf16x3 `split`, live PMC,
+# Lean evidence run of a round (about twelve GPU-minutes): whole GPU suite, smoke, the default bench line (fp32mf `value` + `fp32_direct` + bf16x3 `split`, live PMC,
 # CPU baseline), one clip / one stream lines, rocprofv3 kernel stats of the one-stream and the default command, SQ counter pass.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_evidence_lean.sh r05_final'      -> gpurun_out/<tag>/; copy what is quoted to profiles/
 set -u
@@ -28,7 +28,9 @@ try:
     d=json.load(open('$O/bench_$f.json'))
     sp=d.get('split') or {}
     pr=d['roofline'].get('path_roofline') or {}
+    fd=d.get('fp32_direct') or {}
     print('$f', 'value', round(d['value'],1), 'ms', round(d['ms_per_step'],2), 'frac', round(d['roofline']['frac'],4), 'path', pr.get('frac') and round(pr['frac'],4), 'parity', d['parity_check'] and d['parity_check']['ok'],
+          '| fp32_direct', fd and round(fd['value'],1), fd and fd['parity_check'] and fd['parity_check']['ok'],
           '| split', sp and round(sp['value'],1), sp and round(sp['ms_per_step'],2), sp and sp['parity_check'] and sp['parity_check']['ok'], d['device']['clocks_during_timed_region'].get('sclk_mhz_avg'))
     for r in d['roofline']['classes']+(sp.get('classes') or []): print('   ', r['class'][:44], round(r['ms_per_pass'],2), 'ms', round(r['avg_launch_us'],1),'us', round(r['frac_of_mfma_peak'],4), r['launches_per_pass'])
 except Exception as e:
@@ -43,7 +45,8 @@ prof() { # name args passes
   python $R/tools/prof_summary.py $O/${1}_kernel_stats.csv ${3:-3} 14
   find $O/$1 -name "*kernel_trace.csv" -delete
 }
+prof stream1_fp32mf "--streams 1 --vocoder-precision fp32mf"
 prof stream1_fp32 "--streams 1 --vocoder-precision fp32"
-prof default_both "" 5
+prof default_all "" 7
 cd $R
-bash tools/gpu_sq_pmc.sh $TAG --vocoder-precision fp32 2>&1 | tail -30
+bash tools/gpu_sq_pmc.sh $TAG --vocoder-precision fp32mf 2>&1 | tail -40

@@ -657,10 +657,16 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
                                pack.pack_conv(wt(f"resblocks.{n}.convs2.{m}")), sd[f"resblocks.{n}.convs2.{m}.bias"], rk, d, 0.1, al, be)
                 elif hp["resblock"] == "1":
                     t1 = nb.buf(ch, tm)
+                    # the LeakyReLU between the two convolutions is applied by the FIRST one's epilogue (t1 has no other reader), not by the
+                    # second one's window pass: the same values (max(v, 0.1 v) either way), one in-place LDS pass per 16-channel chunk less
+                    # in every second convolution (round 6; VB_LRELU_IN_WINDOW=1 keeps the old op list for the A/B)
+                    mid_out = not os.environ.get("VB_LRELU_IN_WINDOW")
                     nb.conv(r, t1, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs1.{m}")), sd[f"resblocks.{n}.convs1.{m}.bias"], k=rk,
-                            dil=d, pad=(rk * d - d) // 2, in_act=L.ACT_LRELU, in_slope=0.1)
+                            dil=d, pad=(rk * d - d) // 2, in_act=L.ACT_LRELU, in_slope=0.1,
+                            out_act=L.ACT_LRELU if mid_out else L.ACT_NONE, out_slope=0.1 if mid_out else 0.0)
                     nb.conv(t1, dst, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs2.{m}")), sd[f"resblocks.{n}.convs2.{m}.bias"], k=rk,
-                            pad=(rk - 1) // 2, in_act=L.ACT_LRELU, in_slope=0.1, res=r, alpha=al, beta=be)
+                            pad=(rk - 1) // 2, in_act=L.ACT_NONE if mid_out else L.ACT_LRELU, in_slope=0.0 if mid_out else 0.1, res=r, alpha=al,
+                            beta=be)
                     nb.release(t1)
                 else:
                     nb.conv(r, dst, ch, ch, pack.pack_conv(wt(f"resblocks.{n}.convs.{m}")), sd[f"resblocks.{n}.convs.{m}.bias"], k=rk,
