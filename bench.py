@@ -1028,7 +1028,7 @@ def main():
                 "what": what[sec], "value": total_mel_s / elapsed_sec[sec], "unit": "mel-s/s", "ms_per_step": 1e3 * elapsed_sec[sec] / args.steps,
                 "steps": args.steps, "per_rank_ms": per_rank_ms_sec[sec], "vocoder_precision": sec, "parity_check": parity_sec.get(sec),
                 "classes": table_sec.get(sec, [])}
-        if prim == "fp32mf" and dom_group and table_sec.get("fp32"):
+        if prim == "fp32mf" and dom_group and tuple(dom_group.get("class_ids", ())) == (2, 3) and table_sec.get("fp32"):
             # direct-convolution-equivalent throughput of the dominant group: the flops the direct kernels execute for the same layers (the
             # `fp32` secondary's class table) over this run's group time; `frac` above stays on the flops the minimal-filtering kernels execute
             dgf = sum(r["algorithmic_gflop_per_pass"] for r in table_sec["fp32"])

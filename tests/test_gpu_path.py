@@ -718,7 +718,7 @@ def test_t5_encoder_vs_transformers_golden_and_oracle(ctx):
 
 
 @pytest.mark.parametrize("tag", ["amp1", "amp2"])
-@pytest.mark.parametrize("prec,tol", [("fp32", 5e-5), ("split", 3e-4)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 5e-5), ("fp32mf", 5e-5), ("split", 3e-4)])
 def test_bigvgan_vs_golden_and_oracle(ctx, tag, prec, tol):
     """BigVGAN generator (anti-aliased Snake / SnakeBeta kernel + the shared conv kernels) against the reference's
     own outputs and, on a ragged length, against the oracle."""

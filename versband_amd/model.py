@@ -121,7 +121,7 @@ class AutoencoderKL:
     enc_state: Dict[str, Tensor] = {}
     enc_net = None
     _device = None
-    _precision = "fp32"          # VAE arithmetic: the reference's fp32 (default) or "split" = bf16x3 (set by CFM(vocoder_precision=...))
+    _precision = "fp32mf"        # VAE arithmetic: fp32 with minimal filtering (default), "fp32" = direct fp32 kernels, "split" = bf16x3 (set by CFM(vocoder_precision=...))
 
     def encode(self, x):
         """:49-53  mel [B,80,T_mel] -> DiagonalGaussianDistribution over z [B,embed_dim,T_mel/2] (HIP encoder net)."""
@@ -252,9 +252,10 @@ class FrozenTextVocalEmbedder:
 class CFM:
     def __init__(self, unet_config=None, first_stage_config=None, cond_stage_config=None, timesteps=1000, mel_dim=80,
                  mel_length=848, channels=0, conditioning_key=None, scale_by_std=False, scale_factor=1.0, precision="bf16",
-                 vocoder_precision="fp32", **ignored):
+                 vocoder_precision="fp32mf", **ignored):
         # precision: the DiT ("bf16" production / "split" = bf16x3 parity mode).  vocoder_precision: the first-stage VAE ("fp32" = the
-        # reference's arithmetic on the f32 MFMA, the default since round 4; "split" = bf16x3, <= 3e-5 of it and 1.3x faster end to end)
+        # reference's arithmetic on the f32 MFMA, direct kernels; "fp32mf" = the same with F(2,3) minimal filtering on the 3-tap layers, the default since
+    # round 6; "split" = bf16x3, <= 3e-5 of it and 1.2x faster end to end)
         self.num_timesteps = timesteps
         self.mel_dim, self.mel_length, self.channels = mel_dim, mel_length, channels
         self.sigma_min = 1e-4
@@ -503,9 +504,10 @@ def load_ckpt_state(ckpt_base_dir: str, model_name: str = "model_gen") -> Dict[s
 
 
 class HifiGAN:
-    def __init__(self, vocoder_ckpt, device=None, precision="fp32"):
-        """vocoder/hifigan/hifigan.py:7-18.  precision: "fp32" = the reference's arithmetic (f32 MFMA; default since round 4),
-        "split" = bf16x3 (<= 3e-5 of it, faster)"""
+    def __init__(self, vocoder_ckpt, device=None, precision="fp32mf"):
+        """vocoder/hifigan/hifigan.py:7-18.  precision: "fp32mf" (default since round 6) = the reference's fp32 arithmetic on the f32 MFMA with
+        F(2,3) minimal filtering on the ResBlock convolutions (fp32 products, fewer of them; same bounds against the reference's outputs as
+        "fp32" = the direct fp32 kernels); "split" = bf16x3 (<= 3e-5 of it, faster)"""
         assert precision in ("fp32", "split", "fp32mf"), precision
         self.precision = precision
         base_dir = vocoder_ckpt
@@ -516,7 +518,7 @@ class HifiGAN:
         self._ctx = None
 
     @classmethod
-    def from_state(cls, config: dict, state: dict, device=None, precision="fp32") -> "HifiGAN":
+    def from_state(cls, config: dict, state: dict, device=None, precision="fp32mf") -> "HifiGAN":
         """the generator from an already loaded config + `model_gen` state dict (multi-GPU runs: rank 0 reads <vocoder_ckpt> and the
         weights reach the other ranks through versband_amd.dist.broadcast_state instead of N disk reads)"""
         self = cls.__new__(cls)
