@@ -75,16 +75,18 @@ def rank0_guarded(fn, what: str = "load"):
 
 
 def broadcast_state(state: Union[State, Sequence[State]], src: int = 0, device: torch.device = torch.device("cpu"),
-                    check: bool = True) -> Tuple[Union[State, List[State]], dict]:
+                    check: bool = True, force: bool = False) -> Tuple[Union[State, List[State]], dict]:
     """Every rank returns rank `src`'s tensors, bit for bit.  Ranks other than `src` may pass None / empty dicts: names, shapes and
     dtypes travel first (one small object broadcast), then one flat buffer per dtype.  With world == 1 (or no process group) the
     state comes back unchanged.  check: every rank folds its received bytes into a 64-bit sum and the sums are compared (all_gather) -
-    a broadcast that left any rank with different weights raises instead of generating different audio on that rank."""
+    a broadcast that left any rank with different weights raises instead of generating different audio on that rank.
+    force: run the collectives even in a process group of ONE rank (tests/test_gpu_multirank.py: the only way to execute the RCCL code
+    path - communicator set-up, device-buffer broadcast, all_gather of the checksums - on a 1-GPU box)."""
     import torch.distributed as dist
     single = isinstance(state, dict)
     states: List[State] = [state] if single else [s or {} for s in (state or [])]
     info = {"bytes": 0, "ms": 0.0, "buffers": 0, "checked": False, "backend": None}
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return state, info
     rank = dist.get_rank()
     info["backend"] = dist.get_backend()
