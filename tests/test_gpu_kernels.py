@@ -424,7 +424,9 @@ def test_fp32_dma_conv_is_bit_identical_to_register_staged(lib, monkeypatch, B, 
 MF_CASES = [(2, 128, 1000, 128, 3, 1, 1, True), (1, 256, 752, 256, 3, 3, 1, False), (2, 128, 488, 128, 3, 5, 1, True),
             (1, 128, 1204, 128, 7, 1, 1, True), (2, 256, 360, 256, 7, 3, 1, False), (1, 128, 600, 128, 7, 5, 0, True),
             (1, 256, 724, 256, 11, 1, 1, True), (2, 128, 500, 128, 11, 3, 1, False), (1, 128, 1000, 128, 11, 5, 1, True),
-            (1, 64, 2000, 128, 11, 5, 1, True), (1, 64, 2000, 64, 11, 5, 1, True), (2, 64, 1028, 64, 7, 3, 1, True), (1, 64, 520, 64, 3, 1, 1, False), (1, 384, 304, 192, 3, 1, 0, True), (2, 96, 244, 160, 5, 2, 1, False), (1, 128, 120, 128, 7, 3, 1, True)]
+            (1, 64, 2000, 128, 11, 5, 1, True), (1, 64, 2000, 64, 11, 5, 1, True), (2, 64, 1028, 64, 7, 3, 1, True), (1, 64, 520, 64, 3, 1, 1, False), (1, 384, 304, 192, 3, 1, 0, True), (2, 96, 244, 160, 5, 2, 1, False), (1, 128, 120, 128, 7, 3, 1, True),
+            (1, 384, 1504, 80, 5, 1, 0, False), (1, 128, 8, 128, 3, 1, 1, True), (2, 128, 60, 128, 11, 5, 1, True), (1, 16, 400, 64, 3, 1, 1, False),
+            (3, 64, 132, 192, 7, 1, 0, True)]
 
 
 @pytest.mark.parametrize("B,Ci,T,Co,k,dil,act,res", MF_CASES)

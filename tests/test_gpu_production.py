@@ -179,8 +179,8 @@ def test_c2_second_stream_clip_and_replay_seed_vs_oracle_fixture(prod):
             assert rel <= LATENT_TOL and l1 < MEL_L1_TOL
 
 
-@pytest.mark.parametrize("B", [1, 2])
-def test_path_bits_are_stable_beside_a_second_gpu_process(ctx, prod, B):
+@pytest.mark.parametrize("B,vprec", [(1, "fp32"), (2, "fp32"), (1, "fp32mf"), (2, "fp32mf")])
+def test_path_bits_are_stable_beside_a_second_gpu_process(ctx, prod, B, vprec):
     """Every counted wait of the DMA rings has to hold when the memory system is busy with someone else's traffic - the condition under
     which round 5 found a wait one piece short in the fp32 conv (profiles/r05_conv_tail_race.txt; two ranks sharing a GPU are exactly
     this).  One or two clips - the sizes whose tile choices differ from the 8-clip bench - through sampler (3 Euler steps), fp32 VAE
@@ -188,8 +188,8 @@ def test_path_bits_are_stable_beside_a_second_gpu_process(ctx, prod, B):
     from tests.helpers import beside_load
     from versband_amd.engine import build_hifigan, build_vae_decoder
     hcfg = synth.HifiGanConfig()
-    vae = build_vae_decoder(ctx, prod["sdv"], precision="fp32")
-    voc = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision="fp32")
+    vae = build_vae_decoder(ctx, prod["sdv"], precision=vprec)
+    voc = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision=vprec)
     T, Lc = 752, 80
     inp = clip_batch(B, T, Lc)
     t5 = torch.cat([inp["t5_cond"], inp["t5_uncond"]])
@@ -225,14 +225,15 @@ def _repeat_beside_load(run, names, repeats, seconds):
         assert load.alive(), "the load process ended before the repeats did"
 
 
-def test_vocoder_stage_bits_are_stable_beside_a_second_gpu_process_at_8_clips(ctx, prod):
+@pytest.mark.parametrize("vprec", ["fp32", "fp32mf"])
+def test_vocoder_stage_bits_are_stable_beside_a_second_gpu_process_at_8_clips(ctx, prod, vprec):
     """Round 5's race lived in a path the suite did not stress (verdict item 7): the bench's own vocoder-heavy shape - fp32 VAE decoder
     + fp32 HiFi-GAN over 8 clips of 20 s (the tile choices of the 8-clip launches: 128 x 96 VAE tiles, fused ResBlock pairs, one-round
-    1 x 1 layers) - repeated beside the load process, bitwise."""
+    1 x 1 layers; with "fp32mf" the minimal-filtering kernel's rings on both of its tiles) - repeated beside the load process, bitwise."""
     from versband_amd.engine import build_hifigan, build_vae_decoder
     hcfg = synth.HifiGanConfig()
-    vae = build_vae_decoder(ctx, prod["sdv"], precision="fp32")
-    voc = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision="fp32")
+    vae = build_vae_decoder(ctx, prod["sdv"], precision=vprec)
+    voc = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision=vprec)
     z = clip_batch(8, 752, 80)["x_latent"].to("cuda:0")
 
     def run():
