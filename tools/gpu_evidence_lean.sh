@@ -49,4 +49,5 @@ prof stream1_fp32mf "--streams 1 --vocoder-precision fp32mf"
 prof stream1_fp32 "--streams 1 --vocoder-precision fp32"
 prof default_all "" 7
 cd $R
+timeout 600 python tools/conv_mf_bench.py 8 > $O/mf_layer_bench.txt 2>&1; tail -4 $O/mf_layer_bench.txt
 bash tools/gpu_sq_pmc.sh $TAG --vocoder-precision fp32mf 2>&1 | tail -40
