@@ -114,6 +114,7 @@ def compact_line(out: dict, detail_path: str | None) -> str:
                         "unit": rf.get("unit"), "frac": _r(rf.get("frac"), 4), "traffic": _r(rf.get("traffic")),
                         "algorithmic_bytes_per_launch": _r(rf.get("algorithmic_bytes_per_launch")), "avg_launch_us": _r(rf.get("avg_launch_us"), 5),
                         "path_frac": _r(pr.get("frac"), 4), "path_ideal_ms": _r(pr.get("ideal_ms_per_pass"), 5),
+                        "path_frac_direct_equivalent": _r(pr.get("direct_equivalent_frac"), 4),
                         "groups": [{"group": g["group"].split(" (")[0][:48], "ms_per_pass": _r(g.get("ms_per_pass"), 4), "frac": _r(g.get("frac_of_mfma_peak"), 3)}
                                    for g in (rf.get("groups") or [])]}
     cb = out.get("cpu_baseline")
@@ -1035,6 +1036,12 @@ def main():
             out["roofline"]["direct_equivalent"] = {"achieved": dgf / dom_group["ms_per_pass"], "unit": "TFLOP/s",
                                                     "frac": dgf / dom_group["ms_per_pass"] / dom_group["mfma_peak_tflops"],
                                                     "direct_gflop_per_pass": dgf, "executed_gflop_per_pass": dom_group["algorithmic_gflop_per_pass"]}
+            pr_ = out["roofline"].get("path_roofline")
+            if pr_:
+                # the same for the whole path: the convolution group's ideal time from the DIRECT convolution's flops (comparable with rounds 4-5)
+                ideal_d = pr_["ideal_ms_per_pass"] - dom_group["ideal_ms_per_pass_at_mfma_peak"] + dgf / dom_group["mfma_peak_tflops"]
+                pr_["direct_equivalent_ideal_ms_per_pass"] = ideal_d
+                pr_["direct_equivalent_frac"] = ideal_d / pr_["ms_per_step"]
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             log("cpu baseline (subprocess, bounded)")
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
