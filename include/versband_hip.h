@@ -207,7 +207,8 @@ typedef struct {
     float in_slope, out_slope, alpha, beta, acc_scale;
     const void* w_x3; int ci_pad;   /* optional split-bf16 weights [2][phase][tap][Co][ci_pad]: selects the bf16x3 MFMA conv kernel */
     const void* w2_x3; const float* bias2;   /* VB_OP_RESPAIR: second convolution (w_x3 == NULL: exact-fp32 pair, w and w2_x3 are the fp32
-                                              * packed [k][Ci][Co] weights of the two convolutions; channels 32 / 64 / 128).
+                                              * packed [k][Ci][Co] weights of the two convolutions; channels 32 / 64 / 128; ci_pad == -2: both are
+                                              * minimal-filtering pseudo-tap weights [P][C][C] and the pair runs respair_f32w_kernel, C = 32).
                                               * VB_OP_CONV with w_x3 == NULL: optional fp32 minimal-filtering weights [P][Ci][Co] of the
                                               * same filter (versband_amd/pack.py:pack_conv_mf) - the layer then runs conv1d_f32w_kernel
                                               * (fp32 products, F(2,3): ~1.4-1.5x fewer of them) where its conditions hold */
@@ -325,6 +326,10 @@ int vb_conv1d_f32_mf(const float* x, const float* w, const float* w_mf, const fl
  * packed [k][C ci][C co]; C = 32 / 64 / 128, odd k <= 17, (k-1)*dil <= 60, T % 4 == 0.  Equals two vb_conv1d_f32 launches bit for bit. */
 int vb_respair_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, int B, int C, int T, int k, int dil,
                    float slope, float alpha, float beta, float* out, void* stream);
+/* The same pair with F(2,3) minimal filtering in both convolutions (respair_f32w.hip): w1_mf / w2_mf = pseudo-tap weights [P][C][C]
+ * (pack.py:pack_conv_mf); C = 32, k = 3 / 7 / 11, (k-1)*dil <= 60, T % 4 == 0.  Equals two vb_conv1d_f32_mf launches bit for bit. */
+int vb_respair_f32_mf(const float* x, const float* w1_mf, const float* b1, const float* w2_mf, const float* b2, int B, int C, int T, int k, int dil,
+                      float slope, float alpha, float beta, float* out, void* stream);
 /* counter-based Gumbel draws: out[rows][w], rows = n_branch*B*T */
 int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
                    void* stream);

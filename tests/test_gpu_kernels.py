@@ -558,6 +558,48 @@ def test_fp32_respair_equals_two_fp32_convolutions(lib, B, C, T, k, dil, alpha, 
         assert torch.equal(fused, t2), f"fused pair vs two launches differ by {float((fused - t2).abs().max()):.3e}"
 
 
+@pytest.mark.parametrize("B,T,k,dil,alpha,beta", [(2, 1000, 3, 1, 1.0, 0.0), (1, 472, 11, 5, 1.0 / 3, 1.0), (2, 1000, 7, 3, 1.0, 0.0), (1, 2048, 11, 1, 1.0, 0.0),
+                                                 (1, 228, 11, 5, 1.0, 0.0), (2, 252, 3, 5, 1.0, 0.0), (1, 60, 7, 1, 1.0 / 3, 1.0), (1, 1504, 11, 3, 1.0, 0.0),
+                                                 (1, 736, 3, 3, 1.0, 0.0), (3, 244, 7, 5, 1.0, 0.0)])
+def test_fp32_minimal_filtering_pair_matches_float64_and_the_direct_pair(lib, B, T, k, dil, alpha, beta):
+    """respair_f32w_kernel (round 6: the 32-channel ResBlock1 pair with F(2,3) minimal filtering in both convolutions, intermediate in LDS)
+    against float64 to fp32 roundoff and against the direct fused pair (< 4e-6 of the output's max); workgroup runs of 256 / 240 intermediate
+    positions (d = 1 / 3, 5), both clip ends, T smaller than one run, the accumulate-into-the-MRF-sum form.  It is NOT bit-identical to two
+    conv1d_f32w launches: F(2,3) forms the even and the odd output of a pair by different sums, and which member a position is depends on where
+    the pairs start - the unfused kernel's start at multiples of its tile, the fused kernel's intermediate run starts (k - 1) / 2 positions in
+    front of its outputs - so ~1/3 of the elements differ by one ulp (measured); both are the same distance from float64."""
+    C = 32
+    x = dev(rnd((B, C, T), "wx"))
+    w1, w2 = rnd((C, C, k), "ww1", 1.0 / (C * k) ** 0.5), rnd((C, C, k), "ww2", 1.0 / (C * k) ** 0.5)
+    b1, b2 = dev(rnd((C,), "wb1")), dev(rnd((C,), "wb2"))
+    acc0 = dev(rnd((B, C, T), "wacc"))
+    p1, p2, m1, m2 = dev(pack.pack_conv(w1)), dev(pack.pack_conv(w2)), dev(pack.pack_conv_mf(w1)), dev(pack.pack_conv_mf(w2))
+    fused = acc0.clone()
+    L.check(lib.vb_respair_f32_mf(L.ptr(x), L.ptr(m1), L.ptr(b1), L.ptr(m2), L.ptr(b2), B, C, T, k, dil, 0.1, alpha, beta, L.ptr(fused),
+                                  L.stream_ptr()), "respair_f32_mf")
+    sync()
+    ref64 = F.conv1d(F.leaky_relu(F.conv1d(F.leaky_relu(x.double().cpu(), 0.1), w1.double(), b1.double().cpu(), dilation=dil,
+                                           padding=(k - 1) * dil // 2), 0.1), w2.double(), b2.double().cpu(), padding=(k - 1) // 2) + x.double().cpu()
+    ref64 = alpha * ref64 + beta * acc0.double().cpu()
+    assert torch.isfinite(fused).all()
+    assert rel_l2(fused, ref64) < 2e-6, describe("respair fp32 mf", fused, ref64)
+    if alpha == 1.0 and beta == 0.0:
+        def mf(xin, wpk, wmf, bias, d, act, res):
+            out = torch.full((B, C, T), float("nan"), device="cuda")
+            L.check(lib.vb_conv1d_f32_mf(L.ptr(xin), L.ptr(wpk), L.ptr(wmf), L.ptr(bias), B, C, T, C, k, d, (k - 1) * d // 2, T, act, 0.1,
+                                         L.ptr(res) if res is not None else None, 1.0, 0.0, L.ptr(out), L.stream_ptr()), "conv mf")
+            sync()
+            return out
+        t1 = F.leaky_relu(mf(x, p1, m1, b1, dil, 1, None), 0.1)
+        t2 = mf(t1, p2, m2, b2, 1, 0, x)
+        assert float((fused - t2).abs().max()) < 4e-6 * float(ref64.abs().max()) and rel_l2(t2, ref64) < 2e-6
+        direct = acc0.clone()
+        L.check(lib.vb_respair_f32(L.ptr(x), L.ptr(p1), L.ptr(b1), L.ptr(p2), L.ptr(b2), B, C, T, k, dil, 0.1, alpha, beta, L.ptr(direct),
+                                   L.stream_ptr()), "respair_f32")
+        sync()
+        assert float((fused - direct).abs().max()) < 4e-6 * float(ref64.abs().max())
+
+
 @pytest.mark.parametrize("C,k,dil", [(32, 7, 3), (32, 11, 5), (64, 3, 1), (64, 7, 3), (64, 11, 5)])
 def test_fp32_respair_unrolled_control_flow_equals_the_runtime_loop(lib, monkeypatch, C, k, dil):
     """respair_f32_kernel with the kernel size as a template parameter (a chunk's steps unrolled, wait counts / tap offsets / the tile to

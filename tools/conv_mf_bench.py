@@ -63,3 +63,22 @@ for Ci, Co, T, k, dil, res, act in cases:
           f"({flops * pack.mf_pseudo_taps(k) / (2 * k) / tm / 1e6:6.1f} TF/s executed, {flops / tm / 1e6:6.1f} direct-equivalent)   "
           f"x{td / tm:5.2f}   max|d|/max|y| {err:.2e}", flush=True)
 print(f"sum: direct {tot_d:.0f} us, mf {tot_m:.0f} us, x{tot_d / tot_m:.3f}")
+# fused 32-channel ResBlock pairs: respair_f32_kernel (direct) against respair_f32w_kernel (minimal filtering)
+C, T = 32, 481280
+for k, dil in ((3, 1), (3, 3), (7, 1), (7, 3), (11, 1), (11, 5)):
+    x = torch.randn(B, C, T, device="cuda")
+    w1, w2 = torch.randn(C, C, k) / (C * k) ** 0.5, torch.randn(C, C, k) / (C * k) ** 0.5
+    b1, b2 = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    p1, p2, m1, m2 = pack.pack_conv(w1).cuda(), pack.pack_conv(w2).cuda(), pack.pack_conv_mf(w1).cuda(), pack.pack_conv_mf(w2).cuda()
+    od, om = torch.empty(B, C, T, device="cuda"), torch.empty(B, C, T, device="cuda")
+
+    def pd():
+        L.check(lib.vb_respair_f32(L.ptr(x), L.ptr(p1), L.ptr(b1), L.ptr(p2), L.ptr(b2), B, C, T, k, dil, 0.1, 1.0, 0.0, L.ptr(od), L.stream_ptr()), "pair")
+
+    def pm():
+        L.check(lib.vb_respair_f32_mf(L.ptr(x), L.ptr(m1), L.ptr(b1), L.ptr(m2), L.ptr(b2), B, C, T, k, dil, 0.1, 1.0, 0.0, L.ptr(om), L.stream_ptr()), "pair mf")
+
+    td, tm = timed(pd, 5), timed(pm, 5)
+    flops = 2.0 * 2.0 * B * C * C * k * T
+    print(f"pair C=32 T={T} k={k:2d} d={dil}: direct {td:8.1f} us ({flops / td / 1e6:6.1f} TF/s)   mf {tm:8.1f} us ({flops * pack.mf_pseudo_taps(k) / (2 * k) / tm / 1e6:6.1f} TF/s "
+          f"executed)   x{td / tm:5.2f}   max|d|/max|y| {float((od - om).abs().max() / od.abs().max()):.2e}", flush=True)

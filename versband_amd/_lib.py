@@ -127,6 +127,7 @@ PROTOTYPES = {
     "vb_conv1d_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_float, P, P, P, c_int, P]),
     "vb_conv1d_f32_mf": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_float, c_float, P, P]),
+    "vb_respair_f32_mf": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P]),
     "vb_respair_f32": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P, P]),
     "vb_fill_gumbel": (c_int, [P, c_int, c_int, c_int, c_int, c_u64, c_i64, c_int, c_int, c_int, P]),
     "vb_cast_planes": (c_int, [P, c_i64, P, c_int, P]),

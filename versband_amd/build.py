@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libversband_hip.so")
-SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "conv1d_f32g.hip", "conv1d_f32w.hip", "respair_x3.hip", "respair_f32.hip", "t5.hip", "melnet.hip", "elementwise.hip", "rowlin.hip",
+SOURCES = ["gemm_bf16.hip", "attention.hip", "conv1d_f32.hip", "conv1d_f32g.hip", "conv1d_f32w.hip", "respair_x3.hip", "respair_f32.hip", "respair_f32w.hip", "t5.hip", "melnet.hip", "elementwise.hip", "rowlin.hip",
            "engine.hip"]
 EXPERIMENT_SOURCES = ["score_router.hip"]
 EXPERIMENTS = bool(os.environ.get("VB_BUILD_EXPERIMENTS"))
@@ -29,7 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # SIMD's MFMAs cost matrix-pipe time).  VB_BUILD_AGPR=a.hip,b.hip builds the named files without the flag (the A/B of round 4).
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 _AGPR = set(filter(None, os.environ.get("VB_BUILD_AGPR", "").split(",")))
-EXTRA_FLAGS = {f: list(_VGPR_FORM) for f in ("conv1d_f32g.hip", "conv1d_f32w.hip", "respair_f32.hip", "attention.hip") if f not in _AGPR}
+EXTRA_FLAGS = {f: list(_VGPR_FORM) for f in ("conv1d_f32g.hip", "conv1d_f32w.hip", "respair_f32.hip", "respair_f32w.hip", "attention.hip") if f not in _AGPR}
 # (measured without effect on the split-bf16 kernels - conv1d_f32.hip, respair_x3.hip: 28.96 / 14.24 ms per pass with the flag, 28.91 / 14.34 without -
 #  whose accumulator copies sit in the per-chunk window staging, off the critical path; attention: 12.1 -> 10.9 ms per pass)
 MARKER = b"VB_SOURCE_DIGEST="

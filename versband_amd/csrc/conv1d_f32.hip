@@ -495,7 +495,7 @@ int launch_conv1d(const ConvArgs& a, hipStream_t st) {
                    (!a.res || (reinterpret_cast<uintptr_t>(a.res) & 15) == 0) && !vb_tune().conv_direct_epi) ? 1 : 0;
     // minimal filtering (conv1d_f32w_kernel): the DMA-fed fp32 kernel's conditions + stride 1, shared weights, the staged epilogue, wide layers
     const bool use_mf = a.w_mf && !a.wp && !a.w_bstride && !a.x_bmod && d.in_stride == 1 && d.phases == 1 && !a.upsample2 &&
-                        (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && a.Ci % GK == 0 && a.Co % 4 == 0 && a.Co >= 64 && d.stage_epi &&
+                        (a.in_act == ACT_NONE || a.in_act == ACT_LRELU) && a.Ci % GK == 0 && a.Co % 4 == 0 && a.Co >= 32 && d.stage_epi &&
                         conv1d_f32w_supported(a.ksize, a.dil) && a.T_in % 4 == 0 && a.x_bstride % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w_mf) & 15) == 0 && !vb_tune().conv_mf_off;
     // (flops of the profiler's class table: EXECUTED MFMA work - the minimal-filtering kernel runs pseudo-taps / 2 products per output)

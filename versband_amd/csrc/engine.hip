@@ -752,7 +752,8 @@ static int net_run(vb_ctx* ctx, int which, const float* in, int B, int T, float*
                 r.w1 = o.w; r.w2 = (const float*)o.w2_x3; r.b1 = o.bias; r.b2 = o.bias2;
                 r.slope = o.in_slope; r.alpha = o.alpha; r.beta = o.beta;
                 if (!r.w1 || !r.w2 || !r.b1 || !r.b2 || tlen(o.out) != r.T) VB_FAIL(VB_E_INVALID, "net op %zu: incomplete fp32 respair", oi);
-                VB_TRY(launch_respair_f32(r, st));
+                if (o.ci_pad == -2) VB_TRY(launch_respair_f32w(r, st));      // w / w2_x3 are minimal-filtering pseudo-tap weights (fp32mf)
+                else VB_TRY(launch_respair_f32(r, st));
                 continue;
             }
             RespairArgs r;
@@ -1280,6 +1281,14 @@ int vb_respair_f32(const float* x, const float* w1, const float* b1, const float
     a.x = x; a.out = out; a.B = B; a.C = C; a.T = T; a.k = k; a.dil = dil; a.w1 = w1; a.w2 = w2; a.b1 = b1; a.b2 = b2;
     a.slope = slope; a.alpha = alpha; a.beta = beta;
     return launch_respair_f32(a, (hipStream_t)stream);
+}
+int vb_respair_f32_mf(const float* x, const float* w1_mf, const float* b1, const float* w2_mf, const float* b2, int B, int C, int T, int k, int dil,
+                      float slope, float alpha, float beta, float* out, void* stream) {
+    if (!x || !w1_mf || !b1 || !w2_mf || !b2 || !out || B < 1 || T < 1) VB_FAIL(VB_E_INVALID, "respair_f32_mf: null pointer or B/T < 1");
+    RespairF32Args a;
+    a.x = x; a.out = out; a.B = B; a.C = C; a.T = T; a.k = k; a.dil = dil; a.w1 = w1_mf; a.w2 = w2_mf; a.b1 = b1; a.b2 = b2;
+    a.slope = slope; a.alpha = alpha; a.beta = beta;
+    return launch_respair_f32w(a, (hipStream_t)stream);
 }
 int vb_fill_gumbel(float* out, int B, int n_branch, int T, int width, uint64_t seed, int64_t clip_base, int nfe, int block, int gate,
                    void* stream) {

@@ -143,6 +143,9 @@ struct RespairF32Args {
 };
 bool respair_f32_supported(const RespairF32Args& a);
 int launch_respair_f32(const RespairF32Args& a, hipStream_t st);
+// the same pair with F(2,3) minimal filtering (respair_f32w.hip): w1 / w2 = pseudo-tap weights [P][C][C] (pack.py:pack_conv_mf); C = 32, k = 3 / 7 / 11
+bool respair_f32w_supported(const RespairF32Args& a);
+int launch_respair_f32w(const RespairF32Args& a, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // small kernels

@@ -306,6 +306,13 @@ class NetBuilder:
     def respair(self, x: int, out: int, ch: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, k: int, dil: int, slope: float,
                 alpha: float, beta: float):
         """Fused HiFi-GAN ResBlock1 pair (w1/w2 fp32 packed [k][Ci][Co]); narrow stages only (ch = 32 or 64; fp32 mode: 32 / 64 / 128)."""
+        if self.precision == "fp32" and self.mf and ch == 32 and k in (3, 7, 11) and not os.environ.get("VB_MF_PAIRS_OFF"):
+            # fp32mf: both convolutions of the pair by F(2,3) minimal filtering, intermediate in LDS (respair_f32w.hip); ci_pad = -2 marks the
+            # weights as pseudo-taps [P][C][C]
+            self.ops.append(L.NetOp(kind=L.OP_RESPAIR, x=x, out=out, res=-1, stats=-1, w_buf=-1, w=self._t(pack.pack_conv_mf(w1.permute(2, 1, 0))),
+                                    bias=self._t(b1), bias2=self._t(b2), Ci=ch, Co=ch, ksize=k, dil=dil, in_slope=slope, alpha=alpha, beta=beta,
+                                    w_x3=None, w2_x3=self._t(pack.pack_conv_mf(w2.permute(2, 1, 0))), ci_pad=-2))
+            return
         if self.precision == "fp32":
             # exact-fp32 pair kernel (respair_f32.hip): the packed fp32 weights go in as they are
             self.ops.append(L.NetOp(kind=L.OP_RESPAIR, x=x, out=out, res=-1, stats=-1, w_buf=-1, w=self._t(w1), bias=self._t(b1),
