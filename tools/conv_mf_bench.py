@@ -63,9 +63,9 @@ for Ci, Co, T, k, dil, res, act in cases:
           f"({flops * pack.mf_pseudo_taps(k) / (2 * k) / tm / 1e6:6.1f} TF/s executed, {flops / tm / 1e6:6.1f} direct-equivalent)   "
           f"x{td / tm:5.2f}   max|d|/max|y| {err:.2e}", flush=True)
 print(f"sum: direct {tot_d:.0f} us, mf {tot_m:.0f} us, x{tot_d / tot_m:.3f}")
-# fused 32-channel ResBlock pairs: respair_f32_kernel (direct) against respair_f32w_kernel (minimal filtering)
-C, T = 32, 481280
-for k, dil in ((3, 1), (3, 3), (7, 1), (7, 3), (11, 1), (11, 5)):
+# fused 32- / 64-channel ResBlock pairs: respair_f32_kernel (direct) against respair_f32w_kernel (minimal filtering)
+for C, T, k, dil in [(32, 481280, k, d) for k, d in ((3, 1), (3, 3), (7, 1), (7, 3), (11, 1), (11, 5))] + \
+                    [(64, 240640, k, d) for k, d in ((3, 1), (3, 3), (7, 1), (7, 3), (11, 1), (11, 5))]:
     x = torch.randn(B, C, T, device="cuda")
     w1, w2 = torch.randn(C, C, k) / (C * k) ** 0.5, torch.randn(C, C, k) / (C * k) ** 0.5
     b1, b2 = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
@@ -80,5 +80,5 @@ for k, dil in ((3, 1), (3, 3), (7, 1), (7, 3), (11, 1), (11, 5)):
 
     td, tm = timed(pd, 5), timed(pm, 5)
     flops = 2.0 * 2.0 * B * C * C * k * T
-    print(f"pair C=32 T={T} k={k:2d} d={dil}: direct {td:8.1f} us ({flops / td / 1e6:6.1f} TF/s)   mf {tm:8.1f} us ({flops * pack.mf_pseudo_taps(k) / (2 * k) / tm / 1e6:6.1f} TF/s "
+    print(f"pair C={C} T={T} k={k:2d} d={dil}: direct {td:8.1f} us ({flops / td / 1e6:6.1f} TF/s)   mf {tm:8.1f} us ({flops * pack.mf_pseudo_taps(k) / (2 * k) / tm / 1e6:6.1f} TF/s "
           f"executed)   x{td / tm:5.2f}   max|d|/max|y| {float((od - om).abs().max() / od.abs().max()):.2e}", flush=True)

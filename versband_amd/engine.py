@@ -306,7 +306,7 @@ class NetBuilder:
     def respair(self, x: int, out: int, ch: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, k: int, dil: int, slope: float,
                 alpha: float, beta: float):
         """Fused HiFi-GAN ResBlock1 pair (w1/w2 fp32 packed [k][Ci][Co]); narrow stages only (ch = 32 or 64; fp32 mode: 32 / 64 / 128)."""
-        if self.precision == "fp32" and self.mf and ch == 32 and k in (3, 7, 11) and not os.environ.get("VB_MF_PAIRS_OFF"):
+        if self.precision == "fp32" and self.mf and ch in (32, 64) and k in (3, 7, 11) and not os.environ.get("VB_MF_PAIRS_OFF"):
             # fp32mf: both convolutions of the pair by F(2,3) minimal filtering, intermediate in LDS (respair_f32w.hip); ci_pad = -2 marks the
             # weights as pseudo-taps [P][C][C]
             self.ops.append(L.NetOp(kind=L.OP_RESPAIR, x=x, out=out, res=-1, stats=-1, w_buf=-1, w=self._t(pack.pack_conv_mf(w1.permute(2, 1, 0))),
@@ -622,8 +622,10 @@ def build_hifigan(ctx: Context, sd: Dict[str, Tensor], hp: dict, precision: str 
     driven by the vocoder's config.yaml keys."""
     nb = NetBuilder(ctx.device, precision)
     # exact-fp32 mode: channel counts whose ResBlock1 pairs run fused (respair_f32_kernel); VB_FP32_PAIRS="32,64" / "" for A/B runs
-    # (fp32mf: the 64-channel pairs run faster as two minimal-filtering launches than fused and direct - 1201 -> 1232 mel-s/s on one box,
-    #  profiles/r06_mf_pairs_ab.txt - so only the 32-channel pairs stay fused there)
+    # (fp32mf: the 32-channel pairs run respair_f32w_kernel - minimal filtering in both convolutions, intermediate in LDS; the 64-channel pairs run
+    #  as two unfused minimal-filtering launches: faster than the direct fused pair (1201 -> 1232 mel-s/s) AND than respair_f32w_kernel's 64-channel
+    #  form (VB_FP32_PAIRS=32,64: 1196-1198 against 1224; a 2 x 2 wave grid leaves 16 MFMAs per ring step).  VB_MF_PAIRS_OFF=1 = the direct fused
+    #  pair kernel.  A/Bs: profiles/r06_mf_pairs_ab.txt, profiles/r06_mf_pair32.txt)
     fp32_pairs = tuple(int(v) for v in os.environ.get("VB_FP32_PAIRS", "32" if precision == "fp32mf" else "32,64").split(",") if v.strip())
 
     def wt(name):
