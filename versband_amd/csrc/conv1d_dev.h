@@ -24,6 +24,7 @@ struct ConvDev {
 #ifdef VB_EXPERIMENTS
     int old_tail_wait;       // conv1d_f32g: the round-4 wait count in front of a chunk's first tap (A/B of the round-5 fix)
     int x_nt;                // conv1d_f32g: window DMA with the non-temporal policy (VB_CONV_XNT)
+    int mf_abl;              // conv1d_f32w: timing-only ablations (VB_F32W_ABL: 1 = no in-place window pass, 2 = no epilogue, 4 = no window DMA after the first)
 #endif
     int g_nt, g_nco, g_ntb, g_tbx;   // conv1d_f32g_kernel: time tiles, channel tiles, (time tile, clip, phase) units, units per XCD
 };
