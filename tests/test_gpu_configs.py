@@ -51,6 +51,19 @@ def test_c1_one_clip_ten_steps_vs_oracle(ctx):
     mel_ref = ref_cpu.vae_decode(sdv, z_ref)
     assert rel_l2(z, z_ref) < 1e-3, describe("10-step latent vs oracle", z, z_ref)
     assert float((mel.cpu() - mel_ref).abs().mean()) < 1e-3
+    # the product's default VAE / vocoder arithmetic (round 6: fp32 with F(2,3) minimal filtering) on the same latent, through to the waveform:
+    # north_star's bounds (mel L1 < 1e-3, 1e-3 relative) against the oracle - measured at fp32 roundoff, like the direct fp32 kernels
+    from versband_amd.engine import build_hifigan
+    hcfg = synth.HifiGanConfig()
+    sdh = synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2)
+    wav_ref = ref_cpu.hifigan_forward(sdh, hcfg.as_hparams(), mel_ref)
+    for prec in ("fp32mf", "fp32"):
+        melp = build_vae_decoder(ctx, sdv, precision=prec).run(z)
+        wavp = build_hifigan(ctx, sdh, hcfg.as_hparams(), precision=prec).run(melp)
+        torch.cuda.synchronize()
+        l1, rw = float((melp.cpu() - mel_ref).abs().mean()), rel_l2(wavp, wav_ref)
+        print(f"C1 {prec}: mel L1 {l1:.3e}, wav rel-L2 {rw:.3e}")
+        assert l1 < 1e-3 and rw < 1e-3, f"{prec}: mel L1 {l1:.3e}, wav rel-L2 {rw:.3e}"
 
 
 def _assert_routes_equal_up_to_ties(got, ref_idx, logits, exp_draws, what, tie=2e-5):
