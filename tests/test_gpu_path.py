@@ -690,6 +690,8 @@ def test_fullsize_reference_digests(ctx, engines):
     wavmf = build_hifigan(ctx, synth.make_state_dict(synth.hifigan_shapes(hcfg), SEED + 2), hcfg.as_hparams(), precision="fp32mf").run(melmf)
     torch.cuda.synchronize()
     check_digest(wavmf, g, "voc_wav_", 2e-6)
+    mommf = build_vae_encoder(ctx, synth.make_state_dict(synth.vae_encoder_shapes(vcfg), SEED + 3), precision="fp32mf").run(melmf)
+    check_digest(mommf, g, "vae_moments_", 2e-5)
     assert not torch.equal(wavmf, wav32)                 # (the mode really took the other kernels)
     print(f"fp32mf vs fp32 direct at full size: mel max|d| {float((melmf - mel32).abs().max()):.3e} of {float(mel32.abs().max()):.3f}, "
           f"wav max|d| {float((wavmf - wav32).abs().max()):.3e} of {float(wav32.abs().max()):.3f}")
